@@ -1,0 +1,87 @@
+// Shared device helpers for the MI355X (gfx950) vocoder kernels.
+// Storage types: float, bf16, fp16; arithmetic/accumulation is always fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/mi355x_vocoder.h"
+
+namespace mv {
+
+using bf16 = __hip_bfloat16;
+using f16 = _Float16;
+
+constexpr int WAVE = 64;  // CDNA wavefront
+
+template <typename T> __device__ __forceinline__ float ld(const T* p);
+template <> __device__ __forceinline__ float ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld<bf16>(const bf16* p) {
+  return __uint_as_float(((uint32_t)(*reinterpret_cast<const uint16_t*>(p))) << 16);
+}
+template <> __device__ __forceinline__ float ld<f16>(const f16* p) { return (float)(*p); }
+
+template <typename T> __device__ __forceinline__ void st(T* p, float v);
+template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st<bf16>(bf16* p, float v) { *p = __float2bfloat16(v); }  // RNE, NaN-safe
+template <> __device__ __forceinline__ void st<f16>(f16* p, float v) { *p = (f16)v; }
+
+// round-trip through the storage type (used where the reference order has a stored intermediate)
+template <typename T> __device__ __forceinline__ float rnd(float v) {
+  T t; st<T>(&t, v); return ld<T>(&t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` is >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = (threadIdx.x < nw) ? red[threadIdx.x] : 0.f;
+  if (wid == 0) {
+    r = wave_sum(r);
+    if (lane == 0) red[0] = r;
+  }
+  __syncthreads();
+  return red[0];
+}
+
+enum Act { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SILU = 3 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_LRELU: return v >= 0.f ? v : v * slope;
+    case ACT_TANH: return tanhf(v);
+    case ACT_SILU: return v / (1.f + __expf(-v));
+    default: return v;
+  }
+}
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace mv
+
+// dtype dispatch: BODY sees `T`
+#define MV_DISPATCH(dtype, ...)                                         \
+  switch (dtype) {                                                      \
+    case MV_F32: { using T = float; __VA_ARGS__; break; }               \
+    case MV_BF16: { using T = mv::bf16; __VA_ARGS__; break; }           \
+    case MV_F16: { using T = mv::f16; __VA_ARGS__; break; }             \
+    default: return MV_ERR_DTYPE;                                       \
+  }
+
+#define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
+#define MV_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

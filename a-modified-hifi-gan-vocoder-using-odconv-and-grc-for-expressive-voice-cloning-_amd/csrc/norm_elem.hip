@@ -1,0 +1,387 @@
+// ODConv attention, GroupNorm (two-phase), FiLM, activations, pooling, MPD fold, layout transposes,
+// casts, small dense layers and the GRC+LoRA weight fold.  Generic shapes, NCT layout.
+#include "common.h"
+
+namespace mv {
+
+// ---------------------------------------------------------------- ODConv attention (odconv.py:36-40)
+// one workgroup per sample: wave w reduces channels w, w+nw, ...; then K dot products + softmax.
+template <typename T>
+__global__ __launch_bounds__(256) void odconv_attn_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                          const T* __restrict__ bias, float* __restrict__ alpha,
+                                                          float* __restrict__ pooled, int C, int Tn, int K) {
+  extern __shared__ float sm[];  // [C] means, then [K] logits
+  float* mean = sm;
+  float* logit = sm + C;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const T* xb = x + (long)b * C * Tn;
+  const float inv = 1.f / (float)Tn;
+  for (int c = wid; c < C; c += nw) {
+    float s = 0.f;
+    for (int t = lane; t < Tn; t += 64) s += ld<T>(xb + (long)c * Tn + t);
+    s = wave_sum(s);
+    if (lane == 0) {
+      mean[c] = s * inv;
+      if (pooled) pooled[(long)b * C + c] = s * inv;
+    }
+  }
+  __syncthreads();
+  for (int k = wid; k < K; k += nw) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ld<T>(w + (long)k * C + c) * mean[c];
+    s = wave_sum(s);
+    if (lane == 0) logit[k] = s + (bias ? ld<T>(bias + k) : 0.f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logit[k]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += expf(logit[k] - m);
+    for (int k = 0; k < K; ++k) alpha[(long)b * K + k] = expf(logit[k] - m) / den;
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int C, int Tn, int G, float eps,
+                                                       long x_bs, long x_cs) {
+  __shared__ float red[32];
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int cg = C / G;
+  const T* xb = x + (long)b * x_bs + (long)(g * cg) * x_cs;
+  const long n = (long)cg * Tn;
+  // two-pass (mean, then centred second moment) for accuracy: the data is L2-resident on the second pass
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i / Tn), t = (int)(i % Tn);
+    s += ld<T>(xb + (long)c * x_cs + t);
+  }
+  const float mu = block_sum(s, red) / (float)n;
+  float q = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int c = (int)(i / Tn), t = (int)(i % Tn);
+    const float d = ld<T>(xb + (long)c * x_cs + t) - mu;
+    q += d * d;
+  }
+  const float var = block_sum(q, red) / (float)n;
+  if (threadIdx.x == 0) {
+    mean[blockIdx.x] = mu;
+    rstd[blockIdx.x] = rsqrtf(var + eps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const T* __restrict__ gw,
+                                                       const T* __restrict__ gb, const T* __restrict__ res,
+                                                       const uint8_t* __restrict__ mask, float mask_scale,
+                                                       T* __restrict__ y, int C, int Tn, int G, int act, float slope,
+                                                       long x_bs, long x_cs, long r_bs, long r_cs, long y_bs,
+                                                       long y_cs) {
+  const int bc = blockIdx.y;  // b*C + c
+  const int b = bc / C, c = bc % C;
+  const int g = c / (C / G);
+  const float mu = mean[b * G + g], rs = rstd[b * G + g];
+  const float a = rs * (gw ? ld<T>(gw + c) : 1.f);
+  const float sh = (gb ? ld<T>(gb + c) : 0.f) - mu * a;
+  const T* xr = x + (long)b * x_bs + (long)c * x_cs;
+  const T* rr = res ? res + (long)b * r_bs + (long)c * r_cs : nullptr;
+  const uint8_t* mr = mask ? mask + (long)bc * Tn : nullptr;
+  T* yr = y + (long)b * y_bs + (long)c * y_cs;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
+    float v = apply_act(ld<T>(xr + t) * a + sh, act, slope);
+    if (mr) v = mr[t] ? v * mask_scale : 0.f;
+    if (rr) v += ld<T>(rr + t);
+    st<T>(yr + t, v);
+  }
+}
+
+// ---------------------------------------------------------------- FiLM / scale-shift / activations
+template <typename T>
+__global__ __launch_bounds__(256) void film_kernel(const T* __restrict__ x, const T* __restrict__ proj,
+                                                   T* __restrict__ y, int C, int Tn, int F) {
+  const int bc = blockIdx.y, b = bc / C, c = bc % C;
+  float gam = 1.f, bet = 0.f;
+  if (c < F) {
+    gam = ld<T>(proj + (long)b * 2 * F + c);
+    bet = ld<T>(proj + (long)b * 2 * F + F + c);
+  }
+  const T* xr = x + (long)bc * Tn;
+  T* yr = y + (long)bc * Tn;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x)
+    st<T>(yr + t, ld<T>(xr + t) * gam + bet);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_shift_kernel(const T* __restrict__ x, const T* __restrict__ scale,
+                                                          const T* __restrict__ shift, T* __restrict__ y, int Tn) {
+  const int bc = blockIdx.y;
+  const float s = ld<T>(scale + bc), h = ld<T>(shift + bc);
+  const T* xr = x + (long)bc * Tn;
+  T* yr = y + (long)bc * Tn;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x)
+    st<T>(yr + t, s * ld<T>(xr + t) + h);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                  T* __restrict__ y, long n, int act, float slope) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = apply_act(ld<T>(x + i), act, slope);
+    if (res) v += ld<T>(res + i);
+    st<T>(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int Tn, int To,
+                                                      int s) {
+  const long row = blockIdx.y;
+  const T* xr = x + row * Tn;
+  T* yr = y + row * To;
+  const float inv = 1.f / (float)s;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < To; t += gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int i = 0; i < s; ++i) a += ld<T>(xr + (long)t * s + i);
+    st<T>(yr + t, a * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mpd_fold_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                       int64_t* __restrict__ index, int Tn, int Tp) {
+  const long row = blockIdx.y;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tp; t += gridDim.x * blockDim.x) {
+    st<T>(y + row * Tp + t, t < Tn ? ld<T>(x + row * Tn + t) : 0.f);
+    if (index && row == 0) index[t] = t < Tn ? (int64_t)t : (int64_t)-1;
+  }
+}
+
+// ---------------------------------------------------------------- layout transposes (32x32 LDS tiles)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn) {
+  // x [batch][R][Cn] -> y [batch][Cn][R]
+  __shared__ float tile[32][33];
+  const long base = (long)blockIdx.z * R * Cn;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < Cn) tile[i][tx] = ld<T>(x + base + (long)(r0 + i) * Cn + c0 + tx);
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < Cn && r0 + tx < R) st<T>(y + base + (long)(c0 + i) * R + r0 + tx, tile[tx][i]);
+}
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ x, D* __restrict__ y, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    st<D>(y + i, ld<S>(x + i));
+}
+
+// ---------------------------------------------------------------- small dense layer: one wave per output element
+template <typename T>
+__global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                     const T* __restrict__ b, T* __restrict__ y, int M, int N,
+                                                     int Kd) {
+  const int lane = threadIdx.x & 63;
+  const long o = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (o >= (long)M * N) return;
+  const int m = (int)(o / N), n = (int)(o % N);
+  float s = 0.f;
+  for (int k = lane; k < Kd; k += 64) s += ld<T>(x + (long)m * Kd + k) * ld<T>(w + (long)n * Kd + k);
+  s = wave_sum(s);
+  if (lane == 0) st<T>(y + o, s + (b ? ld<T>(b + n) : 0.f));
+}
+
+// ---------------------------------------------------------------- GRC + LoRA weight fold (grc_lora.py:33-57)
+template <typename T>
+__global__ __launch_bounds__(256) void grc_fold_kernel(const T* __restrict__ conv_w, const T* __restrict__ conv_b,
+                                                       const T* __restrict__ A, const T* __restrict__ Bm,
+                                                       const T* __restrict__ scal, const T* __restrict__ proj_w,
+                                                       const T* __restrict__ proj_b, T* __restrict__ w_eff,
+                                                       T* __restrict__ b_eff, int Cin, int Cout, int ks, int groups,
+                                                       int rank) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = Cout * Cin * ks;
+  const int cin_g = Cin / groups, cout_g = Cout / groups;
+  const float s = ld<T>(scal);
+  if (idx < total) {
+    const int j = idx % ks, c = (idx / ks) % Cin, o = idx / (ks * Cin);
+    float acc = 0.f;
+    for (int op = 0; op < Cout; ++op) {
+      float comb = 0.f;
+      const int g = op / cout_g;
+      if (c / cin_g == g) comb = ld<T>(conv_w + ((long)op * cin_g + (c - g * cin_g)) * ks + j);
+      if (j == ks / 2) {
+        float l = 0.f;
+        for (int r = 0; r < rank; ++r) l += ld<T>(A + (long)c * rank + r) * ld<T>(Bm + (long)r * Cout + op);
+        comb += s * l;
+      }
+      acc += ld<T>(proj_w + (long)o * Cout + op) * comb;
+    }
+    st<T>(w_eff + idx, acc);
+  }
+  if (idx < Cout) {
+    float acc = ld<T>(proj_b + idx);
+    for (int op = 0; op < Cout; ++op) acc += ld<T>(proj_w + (long)idx * Cout + op) * ld<T>(conv_b + op);
+    st<T>(b_eff + idx, acc);
+  }
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+static inline int grid_for(long n, int block = 256, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int mv_abi_version(void) { return 1; }
+extern "C" const char* mv_build_target(void) { return "gfx950"; }
+
+extern "C" int mv_odconv_attn_fwd(const void* x, const void* w, const void* bias, float* alpha, float* pooled, int B,
+                                  int C, int T_, int K, int dtype, void* stream) {
+  MV_CHECK_ARG(x && w && alpha && B > 0 && C > 0 && T_ > 0 && K > 0 && K <= 64);
+  const size_t lds = sizeof(float) * (C + K);
+  MV_CHECK_ARG(lds <= 64 * 1024);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_attn_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream,
+                                        (const T*)x, (const T*)w, (const T*)bias, alpha, pooled, C, T_, K));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_groupnorm_stats(const void* x, float* mean, float* rstd, int B, int C, int T_, int G, float eps,
+                                  long x_bs, long x_cs, int dtype, void* stream) {
+  MV_CHECK_ARG(x && mean && rstd && B > 0 && C > 0 && T_ > 0 && G > 0 && C % G == 0);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(B * G), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)x, mean, rstd, C, T_, G, eps, x_bs, x_cs));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_groupnorm_apply(const void* x, const float* mean, const float* rstd, const void* gw, const void* gb,
+                                  const void* res, const uint8_t* mask, float mask_scale, void* y, int B, int C,
+                                  int T_, int G, int act, float slope, long x_bs, long x_cs, long r_bs, long r_cs,
+                                  long y_bs, long y_cs, int dtype, void* stream) {
+  MV_CHECK_ARG(x && mean && rstd && y && B > 0 && C > 0 && T_ > 0 && G > 0 && C % G == 0 && (long)B * C <= 65535);
+  dim3 grid(grid_for(T_, 256, 64), B * C);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, mean,
+                                        rstd, (const T*)gw, (const T*)gb, (const T*)res, mask, mask_scale, (T*)y, C,
+                                        T_, G, act, slope, x_bs, x_cs, r_bs, r_cs, y_bs, y_cs));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_film_fwd(const void* x, const void* proj, void* y, int B, int C, int T_, int F, int dtype,
+                           void* stream) {
+  MV_CHECK_ARG(x && proj && y && B > 0 && C > 0 && T_ > 0 && F > 0 && (long)B * C <= 65535);
+  dim3 grid(grid_for(T_, 256, 64), B * C);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(film_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                        (const T*)proj, (T*)y, C, T_, F));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_scale_shift_fwd(const void* x, const void* scale, const void* shift, void* y, int B, int C, int T_,
+                                  int dtype, void* stream) {
+  MV_CHECK_ARG(x && scale && shift && y && B > 0 && C > 0 && T_ > 0 && (long)B * C <= 65535);
+  dim3 grid(grid_for(T_, 256, 64), B * C);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(scale_shift_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                        (const T*)scale, (const T*)shift, (T*)y, T_));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_act_fwd(const void* x, const void* res, void* y, long n, int act, float slope, int dtype,
+                          void* stream) {
+  MV_CHECK_ARG(x && y && n > 0);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(act_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)x, (const T*)res, (T*)y, n, act, slope));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_avgpool1d_fwd(const void* x, void* y, long rows, int T_, int s, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && rows > 0 && rows <= 65535 && s > 0 && T_ >= s);
+  const int To = T_ / s;
+  dim3 grid(grid_for(To, 256, 64), (int)rows);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(avgpool_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
+                                        T_, To, s));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mpd_fold(const void* x, void* y, int64_t* index, long rows, int T_, int P, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && rows > 0 && rows <= 65535 && T_ > 0 && P > 0);
+  const int Tp = (T_ % P == 0) ? T_ : T_ + (P - T_ % P);
+  dim3 grid(grid_for(Tp, 256, 64), (int)rows);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(mpd_fold_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                        (T*)y, index, T_, Tp));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0 && cdiv(R, 32) <= 65535);
+  dim3 grid(cdiv(Cn, 32), cdiv(R, 32), batch);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                        (T*)y, R, Cn));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+extern "C" int mv_nct_to_ntc(const void* x, void* y, int B, int C, int T_, int dtype, void* stream) {
+  return transpose_launch(x, y, B, C, T_, dtype, stream);
+}
+extern "C" int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T_, int dtype, void* stream) {
+  return transpose_launch(x, y, B, T_, C, dtype, stream);
+}
+
+template <typename S>
+static int cast_from(const void* x, void* y, int dst, long n, void* stream) {
+  const dim3 g(grid_for(n)), b(256);
+  switch (dst) {
+    case MV_F32: hipLaunchKernelGGL((cast_kernel<S, float>), g, b, 0, (hipStream_t)stream, (const S*)x, (float*)y, n); break;
+    case MV_BF16: hipLaunchKernelGGL((cast_kernel<S, bf16>), g, b, 0, (hipStream_t)stream, (const S*)x, (bf16*)y, n); break;
+    case MV_F16: hipLaunchKernelGGL((cast_kernel<S, f16>), g, b, 0, (hipStream_t)stream, (const S*)x, (f16*)y, n); break;
+    default: return MV_ERR_DTYPE;
+  }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+extern "C" int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream) {
+  MV_CHECK_ARG(x && y && n > 0);
+  switch (src_dtype) {
+    case MV_F32: return cast_from<float>(x, y, dst_dtype, n, stream);
+    case MV_BF16: return cast_from<bf16>(x, y, dst_dtype, n, stream);
+    case MV_F16: return cast_from<f16>(x, y, dst_dtype, n, stream);
+    default: return MV_ERR_DTYPE;
+  }
+}
+
+extern "C" int mv_linear_fwd(const void* x, const void* w, const void* b, void* y, int M, int N, int Kd, int dtype,
+                             void* stream) {
+  MV_CHECK_ARG(x && w && y && M > 0 && N > 0 && Kd > 0);
+  const long outs = (long)M * N;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(linear_kernel<T>, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)x, (const T*)w, (const T*)b, (T*)y, M, N, Kd));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_grc_fold_weights(const void* conv_w, const void* conv_b, const void* lora_A, const void* lora_B,
+                                   const void* lora_scaling, const void* proj_w, const void* proj_b, void* w_eff,
+                                   void* b_eff, int Cin, int Cout, int ks, int groups, int rank, int dtype,
+                                   void* stream) {
+  MV_CHECK_ARG(conv_w && conv_b && lora_A && lora_B && lora_scaling && proj_w && proj_b && w_eff && b_eff);
+  MV_CHECK_ARG(Cin > 0 && Cout > 0 && ks > 0 && (ks & 1) && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && rank > 0);
+  const int total = Cout * Cin * ks;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(grc_fold_kernel<T>, dim3(cdiv(total > Cout ? total : Cout, 256)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)conv_w, (const T*)conv_b, (const T*)lora_A,
+                                        (const T*)lora_B, (const T*)lora_scaling, (const T*)proj_w, (const T*)proj_b,
+                                        (T*)w_eff, (T*)b_eff, Cin, Cout, ks, groups, rank));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -1,0 +1,91 @@
+"""ctypes binding of libmi355x_vocoder.so (C ABI declared in include/mi355x_vocoder.h).
+
+There is NO fallback: if the shared library is missing or a kernel launch fails this module raises.
+The library is built in-tree (``make -C csrc`` or ``__graft_entry__.build()``), next to this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_DIR, "libmi355x_vocoder.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "mi355x_vocoder.h")
+
+MV_F32, MV_BF16, MV_F16 = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SILU = 0, 1, 2, 3
+
+_ERR = {-1: "MV_ERR_ARG (shape/size contract violated)", -2: "MV_ERR_DTYPE", -3: "MV_ERR_UNSUPPORTED"}
+
+_CTYPE = {"int": c_int, "long": c_long, "float": c_float, "size_t": ctypes.c_size_t}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _parse_header(path):
+    """{name: [ctypes argtypes]} for every `int mv_*(...)` prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(c_void_p)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPE[base])
+        protos[name] = (ret, argtypes)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def declared_symbols():
+    global _protos
+    if _protos is None:
+        _protos = _parse_header(HEADER_PATH)
+    return _protos
+
+
+def lib():
+    """Load (once) and return the ctypes library with argtypes set from the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {os.path.join(_PKG_DIR, 'csrc')}` "
+            "(or __graft_entry__.build()). The MI355X vocoder path has no CPU/PyTorch fallback.")
+    l = ctypes.CDLL(LIB_PATH)
+    for name, (ret, argtypes) in declared_symbols().items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name} declared in {HEADER_PATH}") from e
+        fn.argtypes = argtypes
+        fn.restype = c_char_p if ret != "int" else c_int
+    _lib = l
+    return l
+
+
+def check(rc, name):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{name}: {_ERR.get(rc, rc)}")
+    raise RuntimeError(f"{name}: HIP launch failed with hipError_t={rc}")
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    check(fn(*args), name)

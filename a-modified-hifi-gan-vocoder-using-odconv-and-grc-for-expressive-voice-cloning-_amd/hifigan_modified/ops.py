@@ -1,0 +1,262 @@
+"""Tensor-level wrappers over the C ABI (include/mi355x_vocoder.h).
+
+PyTorch is used here only for device memory (output allocation), the current HIP stream and
+autograd bookkeeping; every arithmetic step on activation-sized data is a HIP kernel in
+libmi355x_vocoder.so.  Inputs must live on the GPU: there is no CPU path.
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+from typing import Optional
+
+import torch
+
+from . import _native as N
+
+_DT = {torch.float32: N.MV_F32, torch.bfloat16: N.MV_BF16, torch.float16: N.MV_F16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; use float32, bfloat16 or float16") from None
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mi355x vocoder ops need GPU tensors: this path has no CPU fallback "
+                               "(the CPU oracle lives under oracle/ and is test infrastructure only)")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t: Optional[torch.Tensor]):
+    return None if t is None else (t if t.is_contiguous() else t.contiguous())
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _need_gpu(x)
+    if x.dtype == dtype:
+        return x
+    x = _c(x)
+    y = torch.empty_like(x, dtype=dtype)
+    if x.numel():
+        N.call("mv_cast", _p(x), _dt(x), _p(y), _DT[dtype], x.numel(), _stream())
+    return y
+
+
+class _ParamCache:
+    """Casts of parameters to the activation dtype, keyed on (tensor identity, version) so that an
+    optimizer step (in-place update -> _version bump) invalidates them."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, p: Optional[torch.Tensor], dtype: torch.dtype):
+        if p is None:
+            return None
+        if p.dtype == dtype and p.is_contiguous():
+            return p.detach()
+        key = (id(p), dtype)
+        hit = self._d.get(key)
+        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+            return hit[1]
+        v = cast(p.detach(), dtype)
+        self._d[key] = (p._version, v)
+        return v
+
+
+def odconv_attn(x, w, bias, want_pooled=False):
+    """alpha [B,K] fp32 (+ pooled mean [B,C] fp32)."""
+    _need_gpu(x, w)
+    x = _c(x)
+    B, C, T = x.shape
+    K = w.shape[0]
+    alpha = torch.empty(B, K, device=x.device, dtype=torch.float32)
+    pooled = torch.empty(B, C, device=x.device, dtype=torch.float32) if want_pooled else None
+    N.call("mv_odconv_attn_fwd", _p(x), _p(_c(w)), _p(_c(bias)), _p(alpha), _p(pooled), B, C, T, K, _dt(x), _stream())
+    return (alpha, pooled) if want_pooled else alpha
+
+
+def conv1d(x, w, bias=None, alpha=None, stride=1, padding=0, dilation=1, groups=1, act=N.ACT_NONE, slope=0.1,
+           res=None, out=None, out_channel_offset=0):
+    """Generic (dynamic) conv1d.  w [Cout,Cin/g,ks] or [K,Cout,Cin/g,ks] with alpha [B,K].
+    `out`/`out_channel_offset`: write into a channel slice of a wider [B,Ctot,Tout] buffer."""
+    _need_gpu(x, w)
+    B, Cin, Tin = x.shape
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    nb = 1
+    if w.dim() == 4:
+        nb = w.shape[0]
+        Cout, ks = w.shape[1], w.shape[3]
+    else:
+        Cout, ks = w.shape[0], w.shape[2]
+    Tout = (Tin + 2 * padding - dilation * (ks - 1) - 1) // stride + 1
+    if Tout <= 0:
+        raise RuntimeError(f"conv1d: non-positive output length {Tout}")
+    if out is None:
+        out = torch.empty(B, Cout, Tout, device=x.device, dtype=x.dtype)
+        ysl = out
+    else:
+        ysl = out[:, out_channel_offset:out_channel_offset + Cout]
+    if res is not None:
+        assert res.shape == ysl.shape and res.stride() == ysl.stride(), "res must share y's layout"
+    N.call("mv_conv1d_fwd", _p(x), _p(_c(w)), _p(_c(bias)), _p(alpha), _p(res), _p(ysl),
+           B, Cin, Tin, Cout, Tout, ks, stride, padding, dilation, groups, nb, act, float(slope),
+           x.stride(0), x.stride(1), ysl.stride(0), ysl.stride(1), _dt(x), _stream())
+    return out
+
+
+def conv_transpose1d(x, w, bias=None, alpha=None, stride=1, padding=0, output_padding=0, dilation=1,
+                     act=N.ACT_NONE, slope=0.1):
+    """Generic (dynamic) transposed conv.  w [Cin,Cout,ks] or [K,Cin,Cout,ks]."""
+    _need_gpu(x, w)
+    x = _c(x)
+    B, Cin, Tin = x.shape
+    nb = 1
+    if w.dim() == 4:
+        nb = w.shape[0]
+        Cout, ks = w.shape[2], w.shape[3]
+    else:
+        Cout, ks = w.shape[1], w.shape[2]
+    Tout = (Tin - 1) * stride - 2 * padding + dilation * (ks - 1) + output_padding + 1
+    y = torch.empty(B, Cout, Tout, device=x.device, dtype=x.dtype)
+    N.call("mv_conv_transpose1d_fwd", _p(x), _p(_c(w)), _p(_c(bias)), _p(alpha), _p(y),
+           B, Cin, Tin, Cout, Tout, ks, stride, padding, dilation, nb, act, float(slope), _dt(x), _stream())
+    return y
+
+
+def conv2d(x, w, bias=None, padding=(1, 1), act=N.ACT_NONE, slope=0.1):
+    _need_gpu(x, w)
+    x = _c(x)
+    B, Cin, H, W = x.shape
+    Cout, _, kh, kw = w.shape
+    ph, pw = padding
+    y = torch.empty(B, Cout, H + 2 * ph - kh + 1, W + 2 * pw - kw + 1, device=x.device, dtype=x.dtype)
+    N.call("mv_conv2d_fwd", _p(x), _p(_c(w)), _p(_c(bias)), _p(y), B, Cin, H, W, Cout, kh, kw, ph, pw,
+           act, float(slope), _dt(x), _stream())
+    return y
+
+
+def groupnorm_stats(x, G, eps=1e-5):
+    _need_gpu(x)
+    B, C, T = x.shape
+    assert x.stride(2) == 1
+    mean = torch.empty(B, G, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    N.call("mv_groupnorm_stats", _p(x), _p(mean), _p(rstd), B, C, T, G, float(eps), x.stride(0), x.stride(1),
+           _dt(x), _stream())
+    return mean, rstd
+
+
+def groupnorm_apply(x, mean, rstd, gw, gb, G, act=N.ACT_NONE, slope=0.1, res=None, mask=None, mask_scale=1.0,
+                    out=None):
+    B, C, T = x.shape
+    assert x.stride(2) == 1 and (res is None or res.stride(2) == 1)
+    if out is None:
+        out = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
+    rs0, rs1 = (res.stride(0), res.stride(1)) if res is not None else (0, 0)
+    N.call("mv_groupnorm_apply", _p(x), _p(mean), _p(rstd), _p(_c(gw)), _p(_c(gb)), _p(res), _p(mask),
+           float(mask_scale), _p(out), B, C, T, G, act, float(slope), x.stride(0), x.stride(1), rs0, rs1,
+           out.stride(0), out.stride(1), _dt(x), _stream())
+    return out
+
+
+def grc_fold_weights(conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w, proj_b, groups):
+    _need_gpu(conv_w)
+    Cout, cin_g, ks = conv_w.shape
+    Cin = cin_g * groups
+    rank = lora_A.shape[1]
+    w_eff = torch.empty(Cout, Cin, ks, device=conv_w.device, dtype=conv_w.dtype)
+    b_eff = torch.empty(Cout, device=conv_w.device, dtype=conv_w.dtype)
+    N.call("mv_grc_fold_weights", _p(_c(conv_w)), _p(_c(conv_b)), _p(_c(lora_A)), _p(_c(lora_B)), _p(_c(lora_scaling)),
+           _p(_c(proj_w)), _p(_c(proj_b)), _p(w_eff), _p(b_eff), Cin, Cout, ks, groups, rank, _dt(conv_w), _stream())
+    return w_eff, b_eff
+
+
+def linear(x, w, b=None):
+    _need_gpu(x, w)
+    x = _c(x)
+    M, Kd = x.shape
+    Nn = w.shape[0]
+    y = torch.empty(M, Nn, device=x.device, dtype=x.dtype)
+    N.call("mv_linear_fwd", _p(x), _p(_c(w)), _p(_c(b)), _p(y), M, Nn, Kd, _dt(x), _stream())
+    return y
+
+
+def film(x, proj, F):
+    _need_gpu(x, proj)
+    x = _c(x)
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    N.call("mv_film_fwd", _p(x), _p(_c(proj)), _p(y), B, C, T, F, _dt(x), _stream())
+    return y
+
+
+def scale_shift(x, scale, shift):
+    _need_gpu(x)
+    x = _c(x)
+    B, C, T = x.shape
+    y = torch.empty_like(x)
+    N.call("mv_scale_shift_fwd", _p(x), _p(_c(scale)), _p(_c(shift)), _p(y), B, C, T, _dt(x), _stream())
+    return y
+
+
+def act(x, kind, slope=0.1, res=None):
+    _need_gpu(x)
+    x = _c(x)
+    y = torch.empty_like(x)
+    N.call("mv_act_fwd", _p(x), _p(_c(res)), _p(y), x.numel(), kind, float(slope), _dt(x), _stream())
+    return y
+
+
+def avgpool1d(x, s):
+    _need_gpu(x)
+    x = _c(x)
+    B, C, T = x.shape
+    y = torch.empty(B, C, T // s, device=x.device, dtype=x.dtype)
+    N.call("mv_avgpool1d_fwd", _p(x), _p(y), B * C, T, s, _dt(x), _stream())
+    return y
+
+
+def mpd_fold(x, period, want_index=False):
+    """[B,C,T] -> [B,C,P,ceil(T/P)] (zero right-pad + view; discriminators.py:72-79)."""
+    _need_gpu(x)
+    x = _c(x)
+    B, C, T = x.shape
+    Tp = T if T % period == 0 else T + (period - T % period)
+    index = torch.empty(Tp, device=x.device, dtype=torch.int64) if want_index else None
+    if Tp == T and not want_index:
+        y = x  # the fold of an exact multiple is a pure view
+    else:
+        y = torch.empty(B, C, Tp, device=x.device, dtype=x.dtype)
+        N.call("mv_mpd_fold", _p(x), _p(y), _p(index), B * C, T, period, _dt(x), _stream())
+    y = y.view(B, C, period, Tp // period)
+    return (y, index.view(period, Tp // period)) if want_index else y
+
+
+def nct_to_ntc(x):
+    _need_gpu(x)
+    x = _c(x)
+    B, C, T = x.shape
+    y = torch.empty(B, T, C, device=x.device, dtype=x.dtype)
+    N.call("mv_nct_to_ntc", _p(x), _p(y), B, C, T, _dt(x), _stream())
+    return y
+
+
+def ntc_to_nct(x):
+    _need_gpu(x)
+    x = _c(x)
+    B, T, C = x.shape
+    y = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
+    N.call("mv_ntc_to_nct", _p(x), _p(y), B, C, T, _dt(x), _stream())
+    return y

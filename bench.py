@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s vocoded by the V1 + ODConv + GRC-LoRA generator (BASELINE.json
+configs[1]: B=32 clips x 32 mel frames -> 8192 samples, 80-mel, 22.05 kHz, bf16, inference), one
+process per GPU.  Prints ONE JSON line on rank 0 (contract in the task description).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--no-cpu-baseline]
+
+A "step" is one generator forward over one batch of synthetic mels already resident in HBM.
+Inference shards by minibatch with no data-path collective (replicas only -> weak scaling).
+`roofline` is measured live with HIP events on the launch stream around the MRF ("ResBlock") stage,
+the largest HBM mover of the path (256 B per output sample = 67.1 MB per block per
+batch of 32 in bf16).  `cpu_baseline` times the CPU oracle (reference K-loop formulation, fp32) on
+the host cores of the same box for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "a-modified-hifi-gan-vocoder-using-odconv-and-grc-for-expressive-voice-cloning-_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(sd, n_threads, budget_s=20.0):
+    """Oracle (reference formulation: K shared-weight convs + alpha-weighted sum) on the host cores."""
+    from oracle import vocoder_oracle as O
+    torch.set_num_threads(n_threads)
+    torch.manual_seed(1)
+    B, Tm = 8, 32
+    mel, spk, emo = torch.randn(B, 80, Tm), torch.randn(B, 192), torch.randn(B, 384)
+    with torch.no_grad():
+        O.generator_forward(mel, sd, "", spk, emo)  # warm-up
+        t0, n = time.perf_counter(), 0
+        while True:
+            O.generator_forward(mel, sd, "", spk, emo)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 50:
+                break
+    return {"value": round(B * Tm * n / el, 1), "unit": "mel-frames/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n} forwards of B={B} x {Tm} frames, fp32, oracle K-loop form, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import hifigan_modified as H
+    from hifigan_modified import _native
+    _native.lib()  # no fallback: raise if the HIP library is absent
+
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator()
+    sd_cpu = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.to(dev).to(dtype).train(False)
+    B, Tm = args.batch, args.frames
+    torch.manual_seed(1 + rank)
+    mel = torch.randn(B, 80, Tm, device=dev).to(dtype)
+    spk = torch.randn(B, 192, device=dev).to(dtype)
+    emo = torch.randn(B, 384, device=dev).to(dtype)
+
+    # parity of this very configuration against the oracle (2 clips, so the CPU side stays short)
+    parity = None
+    if rank == 0:
+        from oracle import vocoder_oracle as O
+        with torch.no_grad():
+            w = gen(mel[:2], spk[:2], emo[:2]).float().cpu()
+            ref = O.generator_forward(mel[:2].float().cpu(), sd_cpu, "", spk[:2].float().cpu(), emo[:2].float().cpu())
+        parity = O.rel_l2(w, ref)
+
+    def step():
+        with torch.no_grad():
+            return gen(mel, spk, emo)
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # live roofline of the MRF stage: HIP events on the launch stream (torch's current stream)
+    roof = None
+    if rank == 0:
+        with torch.no_grad():
+            st = gen(mel, spk, emo, return_stages=True)
+            x_in = st["up%d" % (len(gen.upsample_layers) - 1)]
+            blk = gen.mrf_blocks[0]
+            for _ in range(3):
+                blk(x_in)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 20
+            e0.record()
+            for _ in range(reps):
+                blk(x_in)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+        elt = torch.tensor([], dtype=dtype).element_size()
+        alg_bytes = 2 * x_in.numel() * elt          # in + out of the block, once (256 B / sample in bf16)
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "mrf_block", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4)}
+
+    if rank == 0:
+        frames = B * Tm * world * args.steps
+        out = {
+            "metric": "mel-frames/s vocoded (V1 80-mel 22.05kHz generator, ODConv + GRC-LoRA)",
+            "value": round(frames / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "configs[1]: V1 generator + ODConv1d + GRC-LoRA, B=%d x %d mel frames -> %d samples, inference"
+                                   % (B, Tm, Tm * 256), "batch_per_gpu": B, "mel_frames": Tm, "n_mels": 80,
+                       "parallelism": "replicas (batch-sharded, no collective)"},
+            "samples_per_s": round(frames * 256 / elapsed, 1),
+            "parity_rel_l2_vs_oracle": parity,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

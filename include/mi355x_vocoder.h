@@ -1,0 +1,129 @@
+/* mi355x_vocoder.h - C ABI of libmi355x_vocoder.so (MI355X / gfx950 native HiFi-GAN vocoder path).
+ *
+ * Drop-in boundary: the reference has no FFI layer - its boundary is the
+ * nn.Module surface of `hifigan_modified` - so each entry point below is what a binding for that
+ * surface calls, and cites the reference call site (file:line under the reference root) whose
+ * arithmetic it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *  - All tensor pointers are DEVICE pointers.  `dtype` (mv_dtype) is the storage type of
+ *    activations AND weights of that call; accumulation is always fp32.  Small per-sample
+ *    vectors that steer a kernel (ODConv attention alpha, GroupNorm mean/rstd, loss scalars) are fp32.
+ *  - Activations at this boundary are "NCT" (batch, channel, time) contiguous unless a stride
+ *    argument says otherwise, exactly like the reference's tensors.  Entry points whose name ends
+ *    in `_cl` take the private channels-last ("NTC") layout used between fused kernels.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised.
+ *  - Return value: MV_OK (0); MV_ERR_* (<0) for rejected arguments (nothing was launched);
+ *    >0 = the hipError_t of a failed launch.  Nothing throws.
+ *  - Re-entrant; no global state; the caller owns every buffer (workspaces are caller-provided).
+ */
+#ifndef MI355X_VOCODER_H
+#define MI355X_VOCODER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2 } mv_dtype;
+typedef enum { MV_ACT_NONE = 0, MV_ACT_LRELU = 1, MV_ACT_TANH = 2, MV_ACT_SILU = 3 } mv_act;
+
+#define MV_OK 0
+#define MV_ERR_ARG (-1)      /* shape / size / alignment violates the entry point's contract */
+#define MV_ERR_DTYPE (-2)    /* unknown mv_dtype */
+#define MV_ERR_UNSUPPORTED (-3)
+
+/* Library identity: ABI version (bumped on any signature change) and the gfx target it was built for. */
+int mv_abi_version(void);
+const char* mv_build_target(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ODConv kernel attention.   replaces odconv.py:36-40,85 and :136-140,183
+ *   alpha[b,:] = softmax_k( w[k,:] . mean_t x[b,:,t] + bias[k] )          x [B,C,T], w [K,C], bias [K]
+ *   alpha: fp32 [B,K].  pooled (optional, may be NULL): fp32 [B,C] receives mean_t x (saved for backward). */
+int mv_odconv_attn_fwd(const void* x, const void* w, const void* bias, float* alpha, float* pooled,
+                       int B, int C, int T, int K, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (Dynamic) 1-D convolution, generic shapes.   replaces odconv.py:89-106 (nbanks=K, alpha!=NULL) and every
+ * nn.Conv1d on the path (nbanks=1, alpha=NULL): grc_lora.py:33,57,66,160; discriminators.py:97-107; §A output_proj.
+ *   y[b,o,t] = act( sum_k alpha[b,k] ( sum_{c,j} w[k,o,c,j] x[b,c,t*stride-pad+j*dil] + bias[k,o] ) ) + res[b,o,t]
+ *   w [nbanks, Cout, Cin/groups, ks]; bias [nbanks, Cout] or NULL; res (optional) has y's layout.
+ *   x_bs/y_bs: batch strides in elements, x_cs/y_cs: channel strides (time stride is 1) - lets a call read or
+ *   write a channel slice of a wider buffer (the torch.cat of grc_lora.py:159 is written in place). */
+int mv_conv1d_fwd(const void* x, const void* w, const void* bias, const float* alpha, const void* res, void* y,
+                  int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int groups,
+                  int nbanks, int act, float slope,
+                  long x_bs, long x_cs, long y_bs, long y_cs, int dtype, void* stream);
+
+/* (Dynamic) transposed 1-D convolution.   replaces odconv.py:187-204 (+ the nn.LeakyReLU(0.1) of SURVEY §A item 2 when act=LRELU)
+ *   y[b,o,u] = act( sum_k alpha[b,k] ( sum_{c,j: u = t*stride - pad + j*dil} w[k,c,o,j] x[b,c,t] + bias[k,o] ) )
+ *   w [nbanks, Cin, Cout, ks]; Tout = (Tin-1)*stride - 2*pad + dil*(ks-1) + out_pad + 1; groups must be 1. */
+int mv_conv_transpose1d_fwd(const void* x, const void* w, const void* bias, const float* alpha, void* y,
+                            int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                            int nbanks, int act, float slope, int dtype, void* stream);
+
+/* 2-D convolution, stride 1.   replaces discriminators.py:57-65 (Conv2d 3x3 pad 1 + LeakyReLU 0.1)
+ *   x [B,Cin,H,W] -> y [B,Cout,H,W'] ; w [Cout,Cin,kh,kw]; H' = H+2ph-kh+1, W' = W+2pw-kw+1. */
+int mv_conv2d_fwd(const void* x, const void* w, const void* bias, void* y,
+                  int B, int Cin, int H, int W, int Cout, int kh, int kw, int ph, int pw,
+                  int act, float slope, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm, two-phase.   replaces grc_lora.py:58,161 and generator.py:170 (nn.GroupNorm, eps 1e-5)
+ *   stats: mean/rstd fp32 [B,G] over (C/G channels x T) of x (biased variance).
+ *   apply: y = act( (x-mean)*rstd*gw[c] + gb[c] ) * (mask ? mask[b,c,t]*mask_scale : 1) + res
+ *   strides as in mv_conv1d_fwd (x and res may be channel slices). mask: uint8 keep-mask of nn.Dropout (grc_lora.py:162). */
+int mv_groupnorm_stats(const void* x, float* mean, float* rstd, int B, int C, int T, int G, float eps,
+                       long x_bs, long x_cs, int dtype, void* stream);
+int mv_groupnorm_apply(const void* x, const float* mean, const float* rstd, const void* gw, const void* gb,
+                       const void* res, const uint8_t* mask, float mask_scale, void* y,
+                       int B, int C, int T, int G, int act, float slope,
+                       long x_bs, long x_cs, long r_bs, long r_cs, long y_bs, long y_cs, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GRC+LoRA weight folding.   replaces the parameter algebra of grc_lora.py:33-57:
+ *   conv_g(x) + s*(x^T A B)^T followed by the 1x1 output_projection is ONE dense dilated conv with
+ *   w_eff[o,c,j] = sum_o' Wp[o,o'] ( [c in group(o')] Wc[o',c_local,j] + [j==ks/2] s * (A B)[c,o'] ),
+ *   b_eff[o] = sum_o' Wp[o,o'] bc[o'] + bp[o].   ks must be odd.  All parameter tensors in `dtype`; outputs in `dtype`. */
+int mv_grc_fold_weights(const void* conv_w, const void* conv_b, const void* lora_A, const void* lora_B,
+                        const void* lora_scaling, const void* proj_w, const void* proj_b,
+                        void* w_eff, void* b_eff, int Cin, int Cout, int ks, int groups, int rank,
+                        int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small dense layer  y[m,n] = sum_k x[m,k] w[n,k] + b[n]   (nn.Linear of grc_lora.py:108, generator.py:193-194). */
+int mv_linear_fwd(const void* x, const void* w, const void* b, void* y, int M, int N, int Kd, int dtype, void* stream);
+
+/* FiLM modulation.   replaces grc_lora.py:111-129: proj [B,2F] = Linear(cond); gamma = proj[:, :F], beta = proj[:, F:];
+ *   channels c >= F pass through (gamma 1, beta 0); if C < F the first C entries are used.  y = x*gamma + beta, x [B,C,T]. */
+int mv_film_fwd(const void* x, const void* proj, void* y, int B, int C, int T, int F, int dtype, void* stream);
+/* Second-design FiLM (generator.py:193-197): y = scale[b,c]*x + shift[b,c]; scale/shift [B,C] in `dtype`. */
+int mv_scale_shift_fwd(const void* x, const void* scale, const void* shift, void* y, int B, int C, int T,
+                       int dtype, void* stream);
+
+/* Elementwise y = act(x) (+ res).  n elements. */
+int mv_act_fwd(const void* x, const void* res, void* y, long n, int act, float slope, int dtype, void* stream);
+
+/* AvgPool1d(kernel=s, stride=s), floor.   replaces discriminators.py:94,112.  x [B,C,T] -> y [B,C,T/s] */
+int mv_avgpool1d_fwd(const void* x, void* y, long rows, int T, int s, int dtype, void* stream);
+
+/* MPD fold.   replaces discriminators.py:72-79 (F.pad zeros right + view(B,C,P,T'/P)).
+ *   Writes the padded signal y [rows, Tp] (Tp = ceil(T/P)*P) which, viewed as [rows, P, Tp/P], IS the folded
+ *   tensor (row p = contiguous chunk p).  index (optional, int64 [Tp]) receives the source index of every
+ *   folded element, -1 for padding - the bit-exact index map the parity tests compare. */
+int mv_mpd_fold(const void* x, void* y, int64_t* index, long rows, int T, int P, int dtype, void* stream);
+
+/* Layout transposes between the public NCT layout and the private channels-last NTC layout. */
+int mv_nct_to_ntc(const void* x, void* y, int B, int C, int T, int dtype, void* stream);
+int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T, int dtype, void* stream);
+
+/* dtype conversion (fp32 <-> bf16/fp16) of n elements. */
+int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_VOCODER_H */

@@ -1,0 +1,441 @@
+"""CPU oracle for the conditioned HiFi-GAN vocoder hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this file; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may.  It restates, as plain
+functional math on CPU tensors, what the reference's modules compute, and is
+pinned against golden vectors generated from the reference itself (``tests/golden/make_goldens.py``;
+checked in ``tests/test_oracle_vs_golden.py``).
+
+Every function takes the parameters as a flat ``dict[str, Tensor]`` keyed exactly like the
+reference's ``state_dict`` (plus a key prefix), so the same oracle checks a reference-format
+checkpoint and the product modules.  All functions are differentiable through torch autograd, which
+gives the gradient oracle for the backward kernels.  dtype follows the inputs (fp32 or fp64).
+
+Reference lines restated (paths relative to the reference root):
+  odconv_attention / odconv1d            hifigan_modified/odconv.py:36-40,73-108
+  odconv_transpose1d                     hifigan_modified/odconv.py:136-140,172-205
+  grc_lora_block                         hifigan_modified/grc_lora.py:6-68
+  film                                   hifigan_modified/grc_lora.py:79-129
+  mrf_block                              hifigan_modified/grc_lora.py:132-163
+  generator_forward                      SURVEY.md Appendix A (deleted generator, recovered spec)
+  grouped_residual_conv1d                hifigan_modified/generator.py:141-172
+  film2 (FeatureWiseLinearModulation)    hifigan_modified/generator.py:187-199
+  mpd_fold_index / disc2d / disc1d       hifigan_modified/discriminators.py:56-84,94-117
+  lsgan_* losses                         hifigan_modified/complete_vocoder.py:89-184
+  hinge_* losses                         hifigan_modified/conditioned_hifigan.py:254-267
+  mel_spectrogram / mel_l1_loss          defined by this build (reference has only a placeholder:
+                                         complete_vocoder.py:210-212, conditioned_hifigan.py:269-274);
+                                         parameters from speaker_embedding/ecapa_tdnn.py:163-170.
+                                         PARITY UNPINNED against the reference (nothing to pin to);
+                                         checked against torch.stft in tests.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+def _p(sd: SD, prefix: str, name: str) -> Tensor:
+    return sd[prefix + name]
+
+
+# --------------------------------------------------------------------------------------- ODConv
+def odconv_attention(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """alpha[b,:] = softmax_k( W_a . mean_t x[b] + b_a )   (odconv.py:36-40,85).  w: [K,C,1]."""
+    m = x.mean(dim=2)                                   # AdaptiveAvgPool1d(1)
+    z = m @ w[:, :, 0].t() + b                          # Conv1d(C_in, K, 1)
+    return torch.softmax(z, dim=1)                      # [B,K]
+
+
+def odconv1d(x: Tensor, sd: SD, prefix: str, stride=1, padding=0, dilation=1, groups=1,
+             form: str = "kloop") -> Tensor:
+    """y[b] = sum_k alpha[b,k] (conv1d(x[b]; W_k) + bias_k)   (odconv.py:89-106).
+
+    form="kloop" evaluates it as the reference does (K shared-weight convolutions, alpha-weighted
+    sum); form="aggregate" uses the algebraically identical per-sample kernel sum_k alpha W_k."""
+    W = _p(sd, prefix, "kernels")                       # [K, C_out, C_in/groups, ks]
+    bias = _p(sd, prefix, "bias")                       # [K, C_out]
+    alpha = odconv_attention(x, _p(sd, prefix, "kernel_attention.1.weight"),
+                             _p(sd, prefix, "kernel_attention.1.bias"))
+    K = W.shape[0]
+    if form == "kloop":
+        y = None
+        for k in range(K):
+            yk = F.conv1d(x, W[k], bias[k], stride=stride, padding=padding, dilation=dilation, groups=groups)
+            yk = yk * alpha[:, k].view(-1, 1, 1)
+            y = yk if y is None else y + yk
+        return y
+    B = x.shape[0]
+    Wb = torch.einsum("bk,kocj->bocj", alpha, W)        # per-sample kernel
+    bb = alpha @ bias                                   # [B, C_out]
+    ys = [F.conv1d(x[i:i + 1], Wb[i], bb[i], stride=stride, padding=padding, dilation=dilation, groups=groups)
+          for i in range(B)]
+    return torch.cat(ys, dim=0)
+
+
+def odconv_transpose1d(x: Tensor, sd: SD, prefix: str, stride=1, padding=0, output_padding=0,
+                       dilation=1, groups=1, form: str = "kloop") -> Tensor:
+    """Transposed variant, kernels [K, C_in, C_out, ks]   (odconv.py:187-204)."""
+    W = _p(sd, prefix, "kernels")
+    bias = _p(sd, prefix, "bias")
+    alpha = odconv_attention(x, _p(sd, prefix, "kernel_attention.1.weight"),
+                             _p(sd, prefix, "kernel_attention.1.bias"))
+    K = W.shape[0]
+    if form == "kloop":
+        y = None
+        for k in range(K):
+            yk = F.conv_transpose1d(x, W[k], bias[k], stride=stride, padding=padding,
+                                    output_padding=output_padding, dilation=dilation, groups=groups)
+            yk = yk * alpha[:, k].view(-1, 1, 1)
+            y = yk if y is None else y + yk
+        return y
+    B = x.shape[0]
+    Wb = torch.einsum("bk,kcoj->bcoj", alpha, W)
+    bb = alpha @ bias
+    ys = [F.conv_transpose1d(x[i:i + 1], Wb[i], bb[i], stride=stride, padding=padding,
+                             output_padding=output_padding, dilation=dilation, groups=groups)
+          for i in range(B)]
+    return torch.cat(ys, dim=0)
+
+
+# --------------------------------------------------------------------------------------- norms / activations
+def group_norm(x: Tensor, num_groups: int, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
+    """GroupNorm over (C/G channels x all T) per (sample, group), biased variance, affine."""
+    B, C, T = x.shape
+    xg = x.reshape(B, num_groups, (C // num_groups) * T)
+    mu = xg.mean(dim=2, keepdim=True)
+    var = ((xg - mu) ** 2).mean(dim=2, keepdim=True)
+    xn = ((xg - mu) / torch.sqrt(var + eps)).reshape(B, C, T)
+    return xn * weight.view(1, C, 1) + bias.view(1, C, 1)
+
+
+def silu(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+def leaky_relu(x: Tensor, slope: float = 0.1) -> Tensor:
+    return torch.where(x >= 0, x, x * slope)
+
+
+def norm_groups_for(channels: int) -> int:
+    """grc_lora.py:28,154: min(8, C//4) if C >= 4 else 1."""
+    return min(8, channels // 4) if channels >= 4 else 1
+
+
+# --------------------------------------------------------------------------------------- GRC + LoRA, MRF, FiLM
+def grc_lora_block(x: Tensor, sd: SD, prefix: str, dilation: int) -> Tensor:
+    """o = Conv1x1(conv_g(x) + s * (x^T A B)^T); o = SiLU(GN(o)); return o + res(x)   (grc_lora.py:32-68)."""
+    Wc = _p(sd, prefix, "conv.weight")                  # [out, in/G, k]
+    bc = _p(sd, prefix, "conv.bias")
+    out_ch, cin_g, k = Wc.shape
+    in_ch = x.shape[1]
+    G = in_ch // cin_g
+    h = F.conv1d(x, Wc, bc, padding=(k - 1) * dilation // 2, dilation=dilation, groups=G)
+    L = _p(sd, prefix, "lora_A") @ _p(sd, prefix, "lora_B")          # [in, out]
+    lora = torch.einsum("bct,co->bot", x, L)
+    u = h + _p(sd, prefix, "lora_scaling") * lora
+    v = F.conv1d(u, _p(sd, prefix, "output_projection.weight"), _p(sd, prefix, "output_projection.bias"))
+    w = group_norm(v, norm_groups_for(out_ch), _p(sd, prefix, "norm.weight"), _p(sd, prefix, "norm.bias"))
+    a = silu(w)
+    if in_ch != out_ch:
+        res = F.conv1d(x, _p(sd, prefix, "residual_proj.weight"), _p(sd, prefix, "residual_proj.bias"))
+    else:
+        res = x
+    return a + res
+
+
+def mrf_block(x: Tensor, sd: SD, prefix: str, dilations: Sequence[int] = (1, 3, 5),
+              dropout_mask: Optional[Tensor] = None, dropout_p: float = 0.0) -> Tensor:
+    """cat_d GRC_d(x) -> Conv1x1 -> GN -> Dropout -> + x   (grc_lora.py:157-163).
+
+    Eval mode: dropout is the identity.  Train mode parity uses an explicit keep-mask
+    (``dropout_mask`` in {0,1}, scaled by 1/(1-p)) so HIP and oracle can share one mask."""
+    branches = [grc_lora_block(x, sd, f"{prefix}conv_layers.{i}.", d) for i, d in enumerate(dilations)]
+    c = torch.cat(branches, dim=1)
+    f = F.conv1d(c, _p(sd, prefix, "fusion.weight"), _p(sd, prefix, "fusion.bias"))
+    out_ch = f.shape[1]
+    n = group_norm(f, norm_groups_for(out_ch), _p(sd, prefix, "norm.weight"), _p(sd, prefix, "norm.bias"))
+    if dropout_mask is not None:
+        n = n * dropout_mask / (1.0 - dropout_p)
+    return n + x
+
+
+def film_condition(sd: SD, prefix: str, n_channels: int, spk: Optional[Tensor], emo: Optional[Tensor]):
+    """gamma, beta [B, n_channels] per grc_lora.py:82-123 (cat, pad/truncate condition, Linear, chunk,
+    pad gamma with 1 / beta with 0 or truncate)."""
+    if spk is not None and emo is not None:
+        cond = torch.cat([spk, emo], dim=1)
+    elif spk is not None:
+        cond = spk
+    elif emo is not None:
+        cond = emo
+    else:
+        return None, None
+    Wp = _p(sd, prefix, "condition_projection.weight")   # [2F, Cd]
+    bp = _p(sd, prefix, "condition_projection.bias")
+    Cd = Wp.shape[1]
+    if cond.shape[1] < Cd:
+        cond = torch.cat([cond, cond.new_zeros(cond.shape[0], Cd - cond.shape[1])], dim=1)
+    elif cond.shape[1] > Cd:
+        cond = cond[:, :Cd]
+    proj = cond @ Wp.t() + bp
+    Fd = Wp.shape[0] // 2
+    gamma, beta = proj[:, :Fd], proj[:, Fd:]
+    if Fd > n_channels:
+        gamma, beta = gamma[:, :n_channels], beta[:, :n_channels]
+    elif Fd < n_channels:
+        padn = n_channels - Fd
+        gamma = torch.cat([gamma, gamma.new_ones(gamma.shape[0], padn)], dim=1)
+        beta = torch.cat([beta, beta.new_zeros(beta.shape[0], padn)], dim=1)
+    return gamma, beta
+
+
+def film(x: Tensor, sd: SD, prefix: str, spk: Optional[Tensor] = None, emo: Optional[Tensor] = None) -> Tensor:
+    gamma, beta = film_condition(sd, prefix, x.shape[1], spk, emo)
+    if gamma is None:
+        return x
+    return x * gamma.unsqueeze(-1) + beta.unsqueeze(-1)
+
+
+# --------------------------------------------------------------------------------------- generator
+def generator_channel_plan(hidden_channels=512, upsample_factors=(8, 8, 2, 2), groups=4,
+                           resblock_dilation_sizes=((1, 3, 5),) * 3):
+    """Channel widths of the deleted generator's constructor."""
+    ups, cur, n = [], hidden_channels, len(upsample_factors)
+    for i, f in enumerate(upsample_factors):
+        out = max(cur // 2, groups * 2) if i < n - 1 else max(cur, groups * 2)
+        out = out // groups * groups
+        out = max(out, 64)
+        ups.append((cur, out, f))
+        cur = out
+    mrfs = []
+    for dil in resblock_dilation_sizes:
+        ch = max(cur, groups * len(dil) * 2)
+        ch = ch // groups * groups
+        mrfs.append((cur, ch, tuple(dil)))
+        cur = ch
+    return ups, mrfs, cur
+
+
+def generator_forward(mel: Tensor, sd: SD, prefix: str = "", spk: Optional[Tensor] = None,
+                      emo: Optional[Tensor] = None, kernel_size: int = 7, hidden_channels: int = 512,
+                      upsample_factors=(8, 8, 2, 2), resblock_dilation_sizes=((1, 3, 5),) * 3, groups: int = 4,
+                      form: str = "kloop", return_stages: bool = False):
+    """input_proj -> [FiLM] -> 4x(ODConvT + LeakyReLU 0.1) -> 3x MRF -> Conv1d -> tanh (eval mode)."""
+    ups, mrfs, cur = generator_channel_plan(hidden_channels, upsample_factors, groups, resblock_dilation_sizes)
+    st = {}
+    x = odconv1d(mel, sd, prefix + "input_proj.", padding=kernel_size // 2, form=form)
+    st["input_proj"] = x
+    if spk is not None or emo is not None:
+        x = film(x, sd, prefix + "final_film.", spk, emo)
+        st["film"] = x
+    for i, (_, _, f) in enumerate(ups):
+        x = odconv_transpose1d(x, sd, f"{prefix}upsample_layers.{i}.0.", stride=f, padding=f // 2,
+                               output_padding=f % 2, form=form)
+        x = leaky_relu(x, 0.1)
+        st[f"up{i}"] = x
+    for i, (_, _, dil) in enumerate(mrfs):
+        x = mrf_block(x, sd, f"{prefix}mrf_blocks.{i}.", dil)
+        st[f"mrf{i}"] = x
+    Wo = _p(sd, prefix, "output_proj.weight")
+    x = F.conv1d(x, Wo, _p(sd, prefix, "output_proj.bias"), padding=Wo.shape[2] // 2)
+    st["output_proj"] = x
+    x = torch.tanh(x)
+    st["wave"] = x
+    return st if return_stages else x
+
+
+# --------------------------------------------------------------------------------------- second-design blocks
+def grouped_residual_conv1d(x: Tensor, sd: SD, prefix: str, dilation: int, groups: int = 4) -> Tensor:
+    """LeakyReLU(GN_G(Conv1x1(conv_g(x) + alpha * LoRA_g(x)) + x))   (generator.py:141-172)."""
+    Wg = _p(sd, prefix, "grouped_conv.weight")
+    k = Wg.shape[2]
+    h = F.conv1d(x, Wg, _p(sd, prefix, "grouped_conv.bias"), padding=(k - 1) * dilation // 2,
+                 dilation=dilation, groups=groups)
+    A = _p(sd, prefix, "lora_A")                         # [r, C/G]
+    Bm = _p(sd, prefix, "lora_B")                        # [C/G, r]
+    Bsz, C, T = x.shape
+    xg = x.reshape(Bsz, groups, C // groups, T)
+    M = Bm @ A                                           # [C/G, C/G]: l_g = M x_g
+    lora = torch.einsum("oc,bgct->bgot", M, xg).reshape(Bsz, C, T)
+    u = h + _p(sd, prefix, "lora_alpha") * lora
+    m = F.conv1d(u, _p(sd, prefix, "channel_mixer.weight"), _p(sd, prefix, "channel_mixer.bias"))
+    n = group_norm(m + x, groups, _p(sd, prefix, "norm.weight"), _p(sd, prefix, "norm.bias"))
+    return leaky_relu(n, 0.1)
+
+
+def film2(x: Tensor, sd: SD, prefix: str, spk: Tensor, emo: Tensor) -> Tensor:
+    """(W_s e + b_s) * x + (W_h e + b_h), e = spk + emo   (generator.py:187-199)."""
+    e = spk + emo
+    scale = e @ _p(sd, prefix, "scale_proj.weight").t() + _p(sd, prefix, "scale_proj.bias")
+    shift = e @ _p(sd, prefix, "shift_proj.weight").t() + _p(sd, prefix, "shift_proj.bias")
+    return scale.unsqueeze(-1) * x + shift.unsqueeze(-1)
+
+
+# --------------------------------------------------------------------------------------- discriminators
+def mpd_fold_index(T: int, period: int) -> np.ndarray:
+    """int64 [period, ceil(T/period)] source-index map of 'zero right-pad then view(B,C,period,T//period)'
+    (discriminators.py:72-79): entry (p,q) reads sample p*(T'/period)+q, or -1 where that is padding.
+    NOTE: this is the reference's fold (row p = contiguous chunk p), not the canonical HiFi-GAN one."""
+    Tp = T if T % period == 0 else T + (period - T % period)
+    W = Tp // period
+    idx = np.arange(Tp, dtype=np.int64).reshape(period, W)
+    idx[idx >= T] = -1
+    return idx
+
+
+def mpd_fold(x: Tensor, period: int) -> Tensor:
+    B, C, T = x.shape
+    idx = torch.from_numpy(mpd_fold_index(T, period))
+    flat = torch.cat([x, x.new_zeros(B, C, 1)], dim=2)   # slot T holds the zero used for padding
+    gather = torch.where(idx < 0, torch.full_like(idx, T), idx).reshape(-1)
+    return flat[:, :, gather].reshape(B, C, period, -1)
+
+
+def disc2d(x: Tensor, sd: SD, prefix: str, period: int) -> Tensor:
+    """5x Conv2d 3x3 pad 1 (1-32-64-128-256-1), LeakyReLU(0.1) after the first four (discriminators.py:56-84)."""
+    h = mpd_fold(x, period)
+    for li, idx in enumerate((0, 2, 4, 6, 8)):
+        h = F.conv2d(h, _p(sd, prefix, f"conv_layers.{idx}.weight"), _p(sd, prefix, f"conv_layers.{idx}.bias"), padding=1)
+        if li < 4:
+            h = leaky_relu(h, 0.1)
+    return h
+
+
+def disc1d(x: Tensor, sd: SD, prefix: str, scale: int) -> Tensor:
+    """AvgPool1d(s,s) then 5x Conv1d k15 pad 7, LeakyReLU(0.1) after the first four (discriminators.py:94-117)."""
+    B, C, T = x.shape
+    To = T // scale
+    h = x[:, :, :To * scale].reshape(B, C, To, scale).mean(dim=3) if scale > 1 else x
+    for li, idx in enumerate((0, 2, 4, 6, 8)):
+        h = F.conv1d(h, _p(sd, prefix, f"conv_layers.{idx}.weight"), _p(sd, prefix, f"conv_layers.{idx}.bias"), padding=7)
+        if li < 4:
+            h = leaky_relu(h, 0.1)
+    return h
+
+
+def discriminators_forward(real: Tensor, fake: Tensor, sd: SD, prefix: str = "", mpd_prefix="mpd.", msd_prefix="msd.",
+                           periods=(2, 3, 5, 7, 11), scales=(1, 2, 4)) -> Dict[str, List[Tensor]]:
+    """{'mpd_real','mpd_fake','msd_real','msd_fake'} -> lists (discriminators.py:127-151)."""
+    out = {}
+    for tag, wav in (("real", real), ("fake", fake)):
+        out["mpd_" + tag] = [disc2d(wav, sd, f"{prefix}{mpd_prefix}discriminators.{i}.", P) for i, P in enumerate(periods)]
+        out["msd_" + tag] = [disc1d(wav, sd, f"{prefix}{msd_prefix}discriminators.{i}.", s) for i, s in enumerate(scales)]
+    return out
+
+
+# --------------------------------------------------------------------------------------- losses
+def lsgan_discriminator_losses(outs: Dict[str, List[Tensor]]) -> Dict[str, Tensor]:
+    """sum_i mse(D_i(real),1) + mse(D_i(fake),0)   (complete_vocoder.py:145-184)."""
+    r = {}
+    r["mpd_real_loss"] = sum(((o - 1.0) ** 2).mean() for o in outs["mpd_real"])
+    r["mpd_fake_loss"] = sum((o ** 2).mean() for o in outs["mpd_fake"])
+    r["msd_real_loss"] = sum(((o - 1.0) ** 2).mean() for o in outs["msd_real"])
+    r["msd_fake_loss"] = sum((o ** 2).mean() for o in outs["msd_fake"])
+    r["total_loss"] = r["mpd_real_loss"] + r["mpd_fake_loss"] + r["msd_real_loss"] + r["msd_fake_loss"]
+    return r
+
+
+def lsgan_generator_losses(outs: Dict[str, List[Tensor]], mel: Tensor, gen_mel: Tensor,
+                           fm_weight: float = 10.0, mel_weight: float = 45.0) -> Dict[str, Tensor]:
+    """sum mse(D(fake),1) + fm*sum L1(D(fake), stopgrad D(real)) + mel*L1(gen_mel, mel) (complete_vocoder.py:89-143)."""
+    r = {}
+    r["mpd_loss"] = sum(((o - 1.0) ** 2).mean() for o in outs["mpd_fake"])
+    r["msd_loss"] = sum(((o - 1.0) ** 2).mean() for o in outs["msd_fake"])
+    r["mpd_fm_loss"] = sum((f - rr.detach()).abs().mean() for rr, f in zip(outs["mpd_real"], outs["mpd_fake"]))
+    r["msd_fm_loss"] = sum((f - rr.detach()).abs().mean() for rr, f in zip(outs["msd_real"], outs["msd_fake"]))
+    r["mel_loss"] = (gen_mel - mel).abs().mean()
+    r["total_loss"] = (r["mpd_loss"] + r["msd_loss"] + fm_weight * (r["mpd_fm_loss"] + r["msd_fm_loss"])
+                       + mel_weight * r["mel_loss"])
+    return r
+
+
+def hinge_generator_loss(fake_outs: List[Tensor]) -> Tensor:
+    """Intent of conditioned_hifigan.py:254-267 applied per sub-discriminator and summed: mean(relu(1 - D(fake)))."""
+    return sum(torch.relu(1.0 - o).mean() for o in fake_outs)
+
+
+def hinge_discriminator_fake_loss(fake_outs: List[Tensor]) -> Tensor:
+    return sum(torch.relu(1.0 + o).mean() for o in fake_outs)
+
+
+# --------------------------------------------------------------------------------------- mel / STFT loss (defined by the build)
+def hz_to_mel(f):
+    """Slaney scale (linear below 1 kHz, log above) - the librosa default the reference's only mel
+    parameters (speaker_embedding/ecapa_tdnn.py:163-170, librosa.feature.melspectrogram) imply."""
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz, logstep = 1000.0, math.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+
+
+def mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz, logstep = 1000.0, math.log(6.4) / 27.0
+    min_log_mel = min_log_hz / f_sp
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr: int = 22050, n_fft: int = 1024, n_mels: int = 80, fmin: float = 0.0,
+                   fmax: Optional[float] = 8000.0) -> np.ndarray:
+    """Triangular Slaney-normalised filterbank [n_mels, n_fft//2+1], float64."""
+    fmax = sr / 2 if fmax is None else fmax
+    n_bins = n_fft // 2 + 1
+    fft_f = np.linspace(0, sr / 2, n_bins)
+    mel_pts = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_pts)
+    ramps = mel_pts[:, None] - fft_f[None, :]
+    fb = np.zeros((n_mels, n_bins))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        fb[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_pts[2:n_mels + 2] - mel_pts[:n_mels])
+    return fb * enorm[:, None]
+
+
+def hann_window(n: int) -> np.ndarray:
+    """Periodic Hann."""
+    return 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
+
+
+def mel_spectrogram(wave: Tensor, sr: int = 22050, n_fft: int = 1024, hop: int = 256, n_mels: int = 80,
+                    fmin: float = 0.0, fmax: Optional[float] = 8000.0, clamp: float = 1e-5) -> Tensor:
+    """log(clamp(mel_fb @ |rFFT(hann * frame)|, 1e-5)); frames: reflect-pad (n_fft-hop)/2 both sides,
+    hop `hop`, no centre -> exactly T/hop frames (the HiFi-GAN convention).  wave [B,1,T] -> [B,n_mels,T/hop]."""
+    B, _, T = wave.shape
+    padn = (n_fft - hop) // 2
+    w = F.pad(wave, (padn, padn), mode="reflect")[:, 0]                     # [B, T + n_fft - hop]
+    frames = w.unfold(1, n_fft, hop)                                        # [B, n_frames, n_fft]
+    win = torch.from_numpy(hann_window(n_fft)).to(wave.dtype)
+    n = torch.arange(n_fft, dtype=torch.float64)
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+    ang = 2 * math.pi * torch.outer(n, k) / n_fft                           # explicit DFT (no library FFT in the oracle)
+    cosm, sinm = torch.cos(ang).to(wave.dtype), torch.sin(ang).to(wave.dtype)
+    fw = frames * win
+    re, im = fw @ cosm, -(fw @ sinm)
+    mag = torch.sqrt(re * re + im * im + 1e-9)
+    fb = torch.from_numpy(mel_filterbank(sr, n_fft, n_mels, fmin, fmax)).to(wave.dtype)
+    mel = mag @ fb.t()                                                      # [B, n_frames, n_mels]
+    return torch.log(torch.clamp(mel, min=clamp)).transpose(1, 2)
+
+
+def mel_l1_loss(fake_wave: Tensor, target_mel: Tensor, **kw) -> Tensor:
+    return (mel_spectrogram(fake_wave, **kw) - target_mel).abs().mean()
+
+
+# --------------------------------------------------------------------------------------- utilities
+def rel_l2(a: Tensor, b: Tensor) -> float:
+    """||a-b|| / ||b|| in float64."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
