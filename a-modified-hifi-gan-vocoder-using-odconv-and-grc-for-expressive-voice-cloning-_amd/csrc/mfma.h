@@ -1,0 +1,165 @@
+// MFMA operand/accumulator helpers for gfx950 (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// Fragment conventions used by every fused kernel (MI355X guide §3):
+//   A[row = lane&15][k = 8*(lane>>4) + j]   B[k = 8*(lane>>4) + j][col = lane&15]   j = 0..7
+//   D[row = 4*(lane>>4) + r][col = lane&15]                                       r = 0..3
+// We always put OUTPUT CHANNELS on D rows (A = weights) and TIME on D columns (B = activations from a
+// channels-last tile), so one lane owns 4 consecutive output channels of one time step: 8/16-byte
+// channels-last stores, and GroupNorm groups of 4 channels live inside one lane.
+//
+// Storage type T -> operand type:
+//   bf16 -> bf16 MFMA;  f16 -> f16 MFMA;
+//   float -> "bf16x3": every operand is split hi = bf16(x), lo = bf16(x - hi) and a product is
+//            hi*hi + hi*lo + lo*hi (fp32 accumulate), ~2^-16 relative - the fp32-grade path.
+#pragma once
+#include "common.h"
+
+namespace mv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  // RNE via the hardware convert (v_cvt_pk_bf16_f32)
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  f32x2_t f = {a, b};
+  bf16x2_t h = __builtin_convertvector(f, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+  f16x2_t h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <typename T> struct Mma;
+
+template <> struct Mma<bf16> {
+  static constexpr int NSETS = 1;          // operand images per weight fragment
+  static constexpr int ES = 2;             // storage element size
+  struct V { bf16x8_t v; };
+  static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+  }
+  // 8 consecutive storage elements at p (16-byte aligned, LDS or global) -> operand
+  static __device__ __forceinline__ V load_b(const void* p) {
+    V r; r.v = *reinterpret_cast<const bf16x8_t*>(p); return r;
+  }
+  // packed weight fragment: base of this lane's 16 bytes in image 0 (images are `img_stride` bytes apart)
+  static __device__ __forceinline__ V load_a(const char* p, int) { return load_b(p); }
+  static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
+    u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
+    V r; r.v = __builtin_bit_cast(bf16x8_t, u); return r;
+  }
+  static __device__ __forceinline__ void load4(const void* p, float* o) {   // 4 consecutive storage elements
+    const u32x2 u = *reinterpret_cast<const u32x2*>(p);
+    o[0] = bf16_lo(u[0]); o[1] = bf16_hi(u[0]); o[2] = bf16_lo(u[1]); o[3] = bf16_hi(u[1]);
+  }
+  static __device__ __forceinline__ void store4(void* p, const float* v) {
+    u32x2 u = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = u;
+  }
+  static __device__ __forceinline__ float round_store(float v) { return rnd<bf16>(v); }
+};
+
+template <> struct Mma<f16> {
+  static constexpr int NSETS = 1;
+  static constexpr int ES = 2;
+  struct V { f16x8_t v; };
+  static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ V load_b(const void* p) {
+    V r; r.v = *reinterpret_cast<const f16x8_t*>(p); return r;
+  }
+  static __device__ __forceinline__ V load_a(const char* p, int) { return load_b(p); }
+  static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
+    u32x4 u = {pack_f16(x[0], x[1]), pack_f16(x[2], x[3]), pack_f16(y[0], y[1]), pack_f16(y[2], y[3])};
+    V r; r.v = __builtin_bit_cast(f16x8_t, u); return r;
+  }
+  static __device__ __forceinline__ void load4(const void* p, float* o) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x4_t h = *reinterpret_cast<const f16x4_t*>(p);
+    o[0] = (float)h[0]; o[1] = (float)h[1]; o[2] = (float)h[2]; o[3] = (float)h[3];
+  }
+  static __device__ __forceinline__ void store4(void* p, const float* v) {
+    u32x2 u = {pack_f16(v[0], v[1]), pack_f16(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = u;
+  }
+  static __device__ __forceinline__ float round_store(float v) { return rnd<f16>(v); }
+};
+
+template <> struct Mma<float> {
+  static constexpr int NSETS = 2;          // hi image + lo image
+  static constexpr int ES = 4;
+  struct V { bf16x8_t hi, lo; };
+  static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ V split(const float* f) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      h[i] = pack_bf16(f[2 * i], f[2 * i + 1]);
+      l[i] = pack_bf16(f[2 * i] - bf16_lo(h[i]), f[2 * i + 1] - bf16_hi(h[i]));
+    }
+    u32x4 uh = {h[0], h[1], h[2], h[3]}, ul = {l[0], l[1], l[2], l[3]};
+    V r; r.hi = __builtin_bit_cast(bf16x8_t, uh); r.lo = __builtin_bit_cast(bf16x8_t, ul); return r;
+  }
+  static __device__ __forceinline__ V load_b(const void* p) {
+    const f32x4 a = reinterpret_cast<const f32x4*>(p)[0], b = reinterpret_cast<const f32x4*>(p)[1];
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return split(f);
+  }
+  static __device__ __forceinline__ V load_a(const char* p, int img_stride) {
+    V r;
+    r.hi = *reinterpret_cast<const bf16x8_t*>(p);
+    r.lo = *reinterpret_cast<const bf16x8_t*>(p + img_stride);
+    return r;
+  }
+  static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
+    const float f[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return split(f);
+  }
+  static __device__ __forceinline__ void load4(const void* p, float* o) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+  }
+  static __device__ __forceinline__ void store4(void* p, const float* v) {
+    f32x4 a = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = a;
+  }
+  static __device__ __forceinline__ float round_store(float v) { return v; }
+};
+
+// store one weight value into a packed A-fragment image set (pack kernels)
+template <typename T> struct PackW;
+template <> struct PackW<bf16> {
+  static __device__ __forceinline__ void put(char* frag, int img_stride, int lane, int j, float v) {
+    reinterpret_cast<bf16*>(frag + lane * 16)[j] = __float2bfloat16(v);
+  }
+};
+template <> struct PackW<f16> {
+  static __device__ __forceinline__ void put(char* frag, int img_stride, int lane, int j, float v) {
+    reinterpret_cast<f16*>(frag + lane * 16)[j] = (f16)v;
+  }
+};
+template <> struct PackW<float> {
+  static __device__ __forceinline__ void put(char* frag, int img_stride, int lane, int j, float v) {
+    const bf16 h = __float2bfloat16(v);
+    reinterpret_cast<bf16*>(frag + lane * 16)[j] = h;
+    reinterpret_cast<bf16*>(frag + img_stride + lane * 16)[j] = __float2bfloat16(v - __bfloat162float(h));
+  }
+};
+
+constexpr int FRAG_BYTES = 1024;  // one 16x32 operand image: 64 lanes x 16 bytes
+
+}  // namespace mv

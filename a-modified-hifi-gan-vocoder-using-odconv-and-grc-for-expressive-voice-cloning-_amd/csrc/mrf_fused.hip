@@ -1,0 +1,502 @@
+// Fused MultiReceptiveFieldBlock (the generator's "ResBlock") for the 64-channel residual stream.
+//   reference arithmetic: hifigan_modified/grc_lora.py:32-68 (3x GRC_LoRA_Block 64->20, dilations d0,d1,d2)
+//                         + grc_lora.py:157-163 (cat, Conv1d(60,64,1), GroupNorm(8,64), Dropout, +x)
+//
+// Layout: channels-last ("NTC"), x[b][t][64].  Every contraction runs on MFMA 16x16x32 with output channels on
+// D rows and time on D columns (mfma.h).  Per branch, conv_g + LoRA + output_projection are folded (in fp32, at
+// pack time) into one dense 3-tap dilated conv W_eff; the three branches are stacked on the 60(+4 pad) concat
+// rows, so v = W_eff * x is 4 M-tiles over at most 7 distinct taps.  The residual 1x1 (64->60) and the fusion 1x1
+// (60->64) follow; the fusion consumes the accumulators of the previous stage directly as its B operand (the
+// k index of an MFMA may be permuted freely as long as A is packed with the same permutation).
+//
+// GroupNorm needs statistics over all T, twice (GN(5,20) per branch on v, GN(8,64) on the fusion output), so the
+// block is three passes that each READ x ONCE and recompute:  pass 1 -> partial sums of v;  pass 2 -> partial
+// sums of f;  pass 3 -> out = GN8(f) (+dropout) + x.  Nothing but x, out and a few KB of partial sums touches HBM:
+// 3 reads + 1 write of the stream = 4 x 33.5 MB per block at C2 (algorithmic minimum 2 x 33.5 MB).
+// Partial sums are written per workgroup and summed in a fixed order by the consumer: deterministic, no atomics.
+//
+// Workgroup = NWAVES waves, each wave owns NTW*16 consecutive time steps of one sample and stages its own
+// x tile (+halo) into a private LDS region (no block barrier on the data path); packed weights (48 KB) are
+// staged once per workgroup.
+#include "mfma.h"
+#include <cstring>
+
+namespace mv {
+
+constexpr int MRF_C = 64;        // residual-stream channels
+constexpr int MRF_CPD = 20;      // channels per dilation branch
+constexpr int MRF_NBR = 3;
+constexpr int MRF_MAXTAPS = 8;
+constexpr int MRF_CONV_FRAGS = 32, MRF_RES_FRAGS = 8, MRF_FUS_FRAGS = 8;
+constexpr int MRF_TAB_FLOATS = 7 * 64;
+
+struct MrfMeta {
+  int ntaps, halo;
+  int tap_off[MRF_MAXTAPS];
+  int frag_of[4][MRF_MAXTAPS];   // fragment-pair index of (M-tile, tap) or -1
+  int dil[MRF_NBR];
+};
+
+static inline bool mrf_make_meta(const int* dil, MrfMeta* m) {
+  int offs[MRF_MAXTAPS], n = 0;
+  auto add = [&](int o) {
+    for (int i = 0; i < n; ++i) if (offs[i] == o) return;
+    if (n < MRF_MAXTAPS) offs[n++] = o; else n = MRF_MAXTAPS + 1;
+  };
+  add(0);
+  for (int i = 0; i < MRF_NBR; ++i) { if (dil[i] < 1 || dil[i] > 16) return false; add(-dil[i]); add(dil[i]); }
+  if (n > 7) return false;
+  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (offs[j] < offs[i]) { int t = offs[i]; offs[i] = offs[j]; offs[j] = t; }
+  m->ntaps = n; m->halo = 0;
+  for (int i = 0; i < MRF_MAXTAPS; ++i) m->tap_off[i] = i < n ? offs[i] : 0;
+  for (int i = 0; i < MRF_NBR; ++i) { m->dil[i] = dil[i]; if (dil[i] > m->halo) m->halo = dil[i]; }
+  int next = 0;
+  for (int mt = 0; mt < 4; ++mt) {
+    for (int t = 0; t < MRF_MAXTAPS; ++t) m->frag_of[mt][t] = -1;
+    for (int row = 16 * mt; row < 16 * mt + 16 && row < MRF_NBR * MRF_CPD; ++row) {
+      const int br = row / MRF_CPD;
+      for (int t = 0; t < n; ++t)
+        if ((offs[t] == 0 || offs[t] == dil[br] || offs[t] == -dil[br]) && m->frag_of[mt][t] < 0) m->frag_of[mt][t] = -2;
+    }
+    for (int t = 0; t < n; ++t) if (m->frag_of[mt][t] == -2) m->frag_of[mt][t] = next++;
+  }
+  return next * 2 <= MRF_CONV_FRAGS;
+}
+
+template <typename T> constexpr size_t mrf_packed_bytes() {
+  return (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * Mma<T>::NSETS * FRAG_BYTES + MRF_TAB_FLOATS * 4;
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+struct MrfRawParams {   // mirrors mv_mrf_params (include/mi355x_vocoder.h)
+  const void* conv_w[3]; const void* conv_b[3]; const void* lora_A[3]; const void* lora_B[3];
+  const void* lora_scaling[3]; const void* proj_w[3]; const void* proj_b[3];
+  const void* norm_w[3]; const void* norm_b[3]; const void* res_w[3]; const void* res_b[3];
+  const void* fusion_w; const void* fusion_b; const void* norm2_w; const void* norm2_b;
+};
+
+// folded weight of concat row `cc` (branch br, local o), input channel c, branch-local tap jj in {0,1,2}
+template <typename P>
+__device__ float mrf_weff(const MrfRawParams& p, int br, int o, int c, int jj, int rank) {
+  const P* cw = (const P*)p.conv_w[br];   // [20][16][3]
+  const P* A = (const P*)p.lora_A[br];    // [64][rank]
+  const P* Bm = (const P*)p.lora_B[br];   // [rank][20]
+  const P* pw = (const P*)p.proj_w[br];   // [20][20]
+  const float s = ld<P>((const P*)p.lora_scaling[br]);
+  float acc = 0.f;
+  const int gc = c / 16;                  // groups = 4 over 64 input channels
+  for (int op = 0; op < MRF_CPD; ++op) {
+    float comb = 0.f;
+    if (op / 5 == gc) comb = ld<P>(cw + (op * 16 + (c - gc * 16)) * 3 + jj);
+    if (jj == 1) {
+      float l = 0.f;
+      for (int r = 0; r < rank; ++r) l += ld<P>(A + c * rank + r) * ld<P>(Bm + r * MRF_CPD + op);
+      comb += s * l;
+    }
+    acc += ld<P>(pw + o * MRF_CPD + op) * comb;
+  }
+  return acc;
+}
+
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void mrf_pack_kernel(MrfRawParams p, MrfMeta meta, char* __restrict__ out, int rank) {
+  constexpr int FS = Mma<T>::NSETS * FRAG_BYTES;
+  const int nfr = MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS;
+  const int total = nfr * 512;  // 64 lanes x 8 elements per fragment
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total + MRF_TAB_FLOATS; idx += gridDim.x * blockDim.x) {
+    if (idx >= total) {  // float tables
+      const int ti = idx - total, which = ti / 64, cc = ti % 64;
+      float v = 0.f;
+      if (which == 2) v = ld<P>((const P*)p.fusion_b + cc);
+      else if (which == 5) v = ld<P>((const P*)p.norm2_w + cc);
+      else if (which == 6) v = ld<P>((const P*)p.norm2_b + cc);
+      else if (cc < MRF_NBR * MRF_CPD) {
+        const int br = cc / MRF_CPD, o = cc % MRF_CPD;
+        if (which == 0) {  // b_eff = Wp bc + bp
+          v = ld<P>((const P*)p.proj_b[br] + o);
+          for (int op = 0; op < MRF_CPD; ++op)
+            v += ld<P>((const P*)p.proj_w[br] + o * MRF_CPD + op) * ld<P>((const P*)p.conv_b[br] + op);
+        } else if (which == 1) v = ld<P>((const P*)p.res_b[br] + o);
+        else if (which == 3) v = ld<P>((const P*)p.norm_w[br] + o);
+        else if (which == 4) v = ld<P>((const P*)p.norm_b[br] + o);
+      }
+      reinterpret_cast<float*>(out + (size_t)nfr * FS)[ti] = v;
+      continue;
+    }
+    const int f = idx / 512, lane = (idx % 512) / 8, j = idx % 8;
+    const int row16 = lane & 15, g = lane >> 4;
+    float v = 0.f;
+    if (f < MRF_CONV_FRAGS) {
+      const int pair = f >> 1, ks = f & 1;
+      int mt = -1, tap = -1;
+      for (int a = 0; a < 4; ++a) for (int t = 0; t < meta.ntaps; ++t) if (meta.frag_of[a][t] == pair) { mt = a; tap = t; }
+      if (mt >= 0) {
+        const int cc = 16 * mt + row16, c = 32 * ks + 8 * g + j;
+        if (cc < MRF_NBR * MRF_CPD) {
+          const int br = cc / MRF_CPD, o = cc % MRF_CPD, off = meta.tap_off[tap], d = meta.dil[br];
+          const int jj = (off == -d) ? 0 : (off == 0 ? 1 : (off == d ? 2 : -1));
+          if (jj >= 0) v = mrf_weff<P>(p, br, o, c, jj, rank);
+        }
+      }
+    } else if (f < MRF_CONV_FRAGS + MRF_RES_FRAGS) {
+      const int ff = f - MRF_CONV_FRAGS, mt = ff >> 1, ks = ff & 1;
+      const int cc = 16 * mt + row16, c = 32 * ks + 8 * g + j;
+      if (cc < MRF_NBR * MRF_CPD) v = ld<P>((const P*)p.res_w[cc / MRF_CPD] + (cc % MRF_CPD) * MRF_C + c);
+    } else {
+      const int ff = f - MRF_CONV_FRAGS - MRF_RES_FRAGS, mo = ff >> 1, s = ff & 1;
+      const int co = 16 * mo + row16;
+      const int cc = 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3);   // accumulator-order k permutation
+      if (cc < MRF_NBR * MRF_CPD) v = ld<P>((const P*)p.fusion_w + co * (MRF_NBR * MRF_CPD) + cc);
+    }
+    PackW<T>::put(out + (size_t)f * FS, FRAG_BYTES, lane, j, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward passes
+template <typename T, int NWAVES, int NTW, int PASS>
+__global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                          const char* __restrict__ packed, MrfMeta meta,
+                                                          const float* __restrict__ part5, float* __restrict__ part5_out,
+                                                          const float* __restrict__ part8, float* __restrict__ part8_out,
+                                                          const uint8_t* __restrict__ mask, float mask_scale,
+                                                          int Tn, int ntiles, float eps) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int ES = M::ES;
+  constexpr int FS = M::NSETS * FRAG_BYTES;
+  constexpr int RS = MRF_C * ES + 16;                 // padded LDS row stride (bytes)
+  constexpr int WBYTES = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
+  constexpr int TW = NTW * 16;                        // time steps per wave
+
+  extern __shared__ __align__(16) char lds[];
+  char* wl = lds;                                           // packed weights
+  float* tab = reinterpret_cast<float*>(lds + WBYTES);      // 7 x 64 floats
+  float* st5 = tab + MRF_TAB_FLOATS;                        // [16][2] mean, rstd
+  float* st8 = st5 + 32;                                    // [8][2]
+  float* red = st8 + 16;                                    // [NWAVES][16][2] partial sums
+  char* xl = reinterpret_cast<char*>(red + NWAVES * 32);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, tile = blockIdx.x;
+  const int H = meta.halo;
+  const int rows = TW + 2 * H;
+  char* xw = xl + (size_t)wid * rows * RS;
+  const int t0 = (tile * NWAVES + wid) * TW;           // first time step of this wave
+
+  // ---- stage packed weights + tables (whole workgroup)
+  {
+    const int n16 = (WBYTES + MRF_TAB_FLOATS * 4) / 16;
+    const u32x4* src = reinterpret_cast<const u32x4*>(packed);
+    u32x4* dst = reinterpret_cast<u32x4*>(lds);
+    for (int i = tid; i < n16; i += NWAVES * 64) dst[i] = src[i];
+  }
+  // ---- stage this wave's x tile: rows t0-H .. t0+TW+H-1, 64 channels, zero outside [0,Tn)
+  {
+    constexpr int CH = MRF_C * ES / 16;                  // 16-byte chunks per row
+    const T* xb = x + (size_t)b * Tn * MRF_C;
+    for (int i = lane; i < rows * CH; i += 64) {
+      const int r = i / CH, ch = i % CH;
+      const int t = t0 - H + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (t >= 0 && t < Tn) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xb + (size_t)t * MRF_C) + ch * 16);
+      *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = v;
+    }
+  }
+  // ---- GroupNorm statistics from the previous passes' partial sums (fixed summation order)
+  if (PASS >= 2 && tid < 16) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < ntiles; ++i) {
+      s1 += part5[((size_t)(b * ntiles + i) * 16 + tid) * 2];
+      s2 += part5[((size_t)(b * ntiles + i) * 16 + tid) * 2 + 1];
+    }
+    const float n = 4.f * (float)Tn, mu = s1 / n;
+    const float var = fmaxf(s2 / n - mu * mu, 0.f);
+    st5[tid * 2] = mu;
+    st5[tid * 2 + 1] = rsqrtf(var + eps);
+  }
+  if (PASS >= 3 && tid >= 64 && tid < 72) {
+    const int q = tid - 64;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < ntiles; ++i) {
+      s1 += part8[((size_t)(b * ntiles + i) * 8 + q) * 2];
+      s2 += part8[((size_t)(b * ntiles + i) * 8 + q) * 2 + 1];
+    }
+    const float n = 8.f * (float)Tn, mu = s1 / n;
+    const float var = fmaxf(s2 / n - mu * mu, 0.f);
+    st8[q * 2] = mu;
+    st8[q * 2 + 1] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+
+  const float* b_conv = tab, *b_res = tab + 64, *b_fus = tab + 128;
+  const float* g5 = tab + 192, *be5 = tab + 256, *g8 = tab + 320, *be8 = tab + 384;
+
+  // ---- stage 1: v[cc][t] = b_eff + sum_{tap,c} W_eff[cc][tap][c] x[t+off(tap)][c]
+  f32x4 v[4][NTW];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(b_conv + 16 * m + 4 * g);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) v[m][n] = bi;
+  }
+  const char* xcol = xw + (size_t)(col + H) * RS + 8 * g * ES;   // this lane's B-operand base
+  for (int tap = 0; tap < meta.ntaps; ++tap) {
+    const int off = meta.tap_off[tap];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      V bf[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16 + off) * RS + ks * 32 * ES);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int fo = meta.frag_of[m][tap];
+        if (fo >= 0) {
+          const V a = M::load_a(wl + (size_t)(fo * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
+        }
+      }
+    }
+  }
+
+  if (PASS == 1) {
+    // partial sums of v per GN(5,20) group: concat rows 16m+4g..+3 are exactly group 4m+g
+    float s1[4], s2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      s1[m] = 0.f; s2[m] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const bool ok = (t0 + n * 16 + col) < Tn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float q = ok ? v[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1[m] += __shfl_xor(s1[m], o, 64); s2[m] += __shfl_xor(s2[m], o, 64); }
+    }
+    if (col == 0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { red[(wid * 16 + 4 * m + g) * 2] = s1[m]; red[(wid * 16 + 4 * m + g) * 2 + 1] = s2[m]; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float a = 0.f;
+      for (int w = 0; w < NWAVES; ++w) a += red[w * 32 + tid];
+      part5_out[(size_t)(b * ntiles + tile) * 32 + tid] = a;
+    }
+    return;
+  }
+
+  // ---- stage 2: a = SiLU(GN5(v)) ; r = b_res + W_res x ; c = a + r   (c overwrites v)
+  {
+    f32x4 rr[4][NTW];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(b_res + 16 * m + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) rr[m][n] = bi;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      V bf[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16) * RS + ks * 32 * ES);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) rr[m][n] = M::mma(a, bf[n], rr[m][n]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float mu = st5[(4 * m + g) * 2], rs = st5[(4 * m + g) * 2 + 1];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(g5 + 16 * m + 4 * g);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(be5 + 16 * m + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sc = rs * ga[r], sh = be[r] - mu * sc;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const float w = v[m][n][r] * sc + sh;
+          v[m][n][r] = w / (1.f + __expf(-w)) + rr[m][n][r];
+        }
+      }
+    }
+  }
+
+  // ---- stage 3: f[co][t] = b_fus + sum_cc W_fus[co][cc] c[cc][t]   (c fed straight from the accumulators)
+  f32x4 f[4][NTW];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const f32x4 bi = *reinterpret_cast<const f32x4*>(b_fus + 16 * m + 4 * g);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) f[m][n] = bi;
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    V cb[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) cb[n] = M::from_acc(v[2 * s][n], v[2 * s + 1][n]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(a, cb[n], f[m][n]);
+    }
+  }
+
+  if (PASS == 2) {
+    // partial sums of f per GN(8,64) group: rows 16m+4g+r -> group 2m + (g>>1)
+    float s1[4], s2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      s1[m] = 0.f; s2[m] = 0.f;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const bool ok = (t0 + n * 16 + col) < Tn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float q = ok ? f[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
+      }
+#pragma unroll
+      for (int o = 1; o <= 16; o <<= 1) { s1[m] += __shfl_xor(s1[m], o, 64); s2[m] += __shfl_xor(s2[m], o, 64); }
+    }
+    if (col == 0 && (g & 1) == 0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { red[(wid * 8 + 2 * m + (g >> 1)) * 2] = s1[m]; red[(wid * 8 + 2 * m + (g >> 1)) * 2 + 1] = s2[m]; }
+    }
+    __syncthreads();
+    if (tid < 16) {
+      float a = 0.f;
+      for (int w = 0; w < NWAVES; ++w) a += red[w * 16 + tid];
+      part8_out[(size_t)(b * ntiles + tile) * 16 + tid] = a;
+    }
+    return;
+  }
+
+  // ---- stage 4 (pass 3): out = GN8(f) * keep/(1-p) + x
+  T* ob = out + (size_t)b * Tn * MRF_C;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int q = 2 * m + (g >> 1);
+    const float mu = st8[q * 2], rs = st8[q * 2 + 1];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(g8 + 16 * m + 4 * g);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(be8 + 16 * m + 4 * g);
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int t = t0 + n * 16 + col;
+      if (t < Tn) {
+        float xr[4], o[4];
+        M::load4(xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES, xr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sc = rs * ga[r];
+          float w = f[m][n][r] * sc + (be[r] - mu * sc);
+          if (mask) w = mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r] ? w * mask_scale : 0.f;
+          o[r] = w + xr[r];
+        }
+        M::store4(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + (16 * m + 4 * g) * ES, o);
+      }
+    }
+  }
+}
+
+template <typename T, int NWAVES, int NTW>
+static int mrf_launch(const void* x, void* out, const void* packed, const MrfMeta& meta, float* ws,
+                      const uint8_t* mask, float mask_scale, int B, int Tn, float eps, hipStream_t stream) {
+  using M = Mma<T>;
+  constexpr int FS = M::NSETS * FRAG_BYTES;
+  constexpr int RS = MRF_C * M::ES + 16;
+  const int tile_t = NWAVES * NTW * 16;
+  const int ntiles = cdiv(Tn, tile_t);
+  const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
+                     (size_t)NWAVES * 32 * 4 + (size_t)NWAVES * (NTW * 16 + 2 * meta.halo) * RS;
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  float* part5 = ws;
+  float* part8 = ws + (size_t)B * ntiles * 32;
+  dim3 grid(ntiles, B), block(NWAVES * 64);
+  auto k1 = mrf_kernel<T, NWAVES, NTW, 1>;
+  auto k2 = mrf_kernel<T, NWAVES, NTW, 2>;
+  auto k3 = mrf_kernel<T, NWAVES, NTW, 3>;
+  static size_t lds_set = 0;   // per instantiation: raise the dynamic-LDS limit once (and again if a larger halo needs it)
+  if (lds > lds_set) {
+    (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(k1, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, nullptr, part5,
+                     nullptr, nullptr, nullptr, 1.f, Tn, ntiles, eps);
+  hipLaunchKernelGGL(k2, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
+                     nullptr, part8, nullptr, 1.f, Tn, ntiles, eps);
+  hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
+                     part8, nullptr, mask, mask_scale, Tn, ntiles, eps);
+  return MV_OK;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" size_t mv_mrf_packed_bytes(int dtype) {
+  switch (dtype) {
+    case MV_F32: return mrf_packed_bytes<float>();
+    case MV_BF16: return mrf_packed_bytes<bf16>();
+    case MV_F16: return mrf_packed_bytes<f16>();
+    default: return 0;
+  }
+}
+
+// tile geometry per storage type: bf16/f16: 8 waves x 64 steps; fp32 (bf16x3 operands, 2x LDS): 4 waves x 32 steps
+static inline int mrf_tile_t(int dtype) { return dtype == MV_F32 ? 4 * 2 * 16 : 8 * 4 * 16; }
+
+extern "C" size_t mv_mrf_workspace_bytes(int B, int T_, int dtype) {
+  const int ntiles = cdiv(T_, mrf_tile_t(dtype));
+  return (size_t)B * ntiles * (32 + 16) * sizeof(float);
+}
+
+template <typename T>
+static int mrf_pack_dispatch(const mv_mrf_params* prm, const MrfMeta& meta, void* packed, int rank, int param_dtype,
+                             hipStream_t stream) {
+  MrfRawParams p;
+  static_assert(sizeof(MrfRawParams) == sizeof(mv_mrf_params), "mv_mrf_params layout");
+  std::memcpy(&p, prm, sizeof(p));
+  const dim3 grid(48), block(256);
+  switch (param_dtype) {
+    case MV_F32: hipLaunchKernelGGL((mrf_pack_kernel<T, float>), grid, block, 0, stream, p, meta, (char*)packed, rank); break;
+    case MV_BF16: hipLaunchKernelGGL((mrf_pack_kernel<T, bf16>), grid, block, 0, stream, p, meta, (char*)packed, rank); break;
+    case MV_F16: hipLaunchKernelGGL((mrf_pack_kernel<T, f16>), grid, block, 0, stream, p, meta, (char*)packed, rank); break;
+    default: return MV_ERR_DTYPE;
+  }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mrf_pack(const mv_mrf_params* params, int param_dtype, const int* dilations, int lora_rank,
+                           void* packed, int dtype, void* stream) {
+  MV_CHECK_ARG(params && dilations && packed && lora_rank > 0);
+  MrfMeta meta;
+  if (!mrf_make_meta(dilations, &meta)) return MV_ERR_UNSUPPORTED;
+  MV_DISPATCH(dtype, return mrf_pack_dispatch<T>(params, meta, packed, lora_rank, param_dtype, (hipStream_t)stream));
+  return MV_OK;
+}
+
+extern "C" int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int* dilations, void* workspace,
+                                   const uint8_t* dropout_mask, float mask_scale, int B, int T_, float eps, int dtype,
+                                   void* stream) {
+  MV_CHECK_ARG(x && out && packed && dilations && workspace && B > 0 && B <= 65535 && T_ > 0 && x != out);
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+  MrfMeta meta;
+  if (!mrf_make_meta(dilations, &meta)) return MV_ERR_UNSUPPORTED;
+  int rc;
+  switch (dtype) {
+    case MV_F32: rc = mrf_launch<float, 4, 2>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
+    case MV_BF16: rc = mrf_launch<bf16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
+    case MV_F16: rc = mrf_launch<f16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
+    default: return MV_ERR_DTYPE;
+  }
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

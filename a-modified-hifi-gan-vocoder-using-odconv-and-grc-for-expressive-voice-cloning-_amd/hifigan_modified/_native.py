@@ -30,8 +30,9 @@ def _parse_header(path):
     """{name: [ctypes argtypes]} for every `int mv_*(...)` prototype in the header."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"typedef\s+struct[^{]*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(mv_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != "void":
@@ -73,7 +74,7 @@ def lib():
         except AttributeError as e:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name} declared in {HEADER_PATH}") from e
         fn.argtypes = argtypes
-        fn.restype = c_char_p if ret != "int" else c_int
+        fn.restype = {"int": c_int, "size_t": ctypes.c_size_t}.get(ret, c_char_p)
     _lib = l
     return l
 
@@ -89,3 +90,10 @@ def check(rc, name):
 def call(name, *args):
     fn = getattr(lib(), name)
     check(fn(*args), name)
+
+
+class MrfParams(ctypes.Structure):
+    """mv_mrf_params (include/mi355x_vocoder.h)."""
+    _fields_ = ([(n, c_void_p * 3) for n in ("conv_w", "conv_b", "lora_A", "lora_B", "lora_scaling", "proj_w",
+                                            "proj_b", "norm_w", "norm_b", "res_w", "res_b")]
+                + [(n, c_void_p) for n in ("fusion_w", "fusion_b", "norm2_w", "norm2_b")])

@@ -127,9 +127,16 @@ def grc_lora_block(x, blk, out=None, out_channel_offset=0):
     return _track("grc_lora_block", out, x, *blk.parameters())
 
 
-def mrf_block(x, blk):
-    """grc_lora.py:157-163.  The three branches write straight into the channel slices of the concat
-    buffer (no torch.cat copy); fusion conv, GroupNorm, dropout and the residual add follow."""
+def mrf_block(x, blk, force_generic=False):
+    """grc_lora.py:157-163.  64-channel blocks of the generator's shape run the fused MFMA kernel
+    (csrc/mrf_fused.hip) in channels-last layout; any other shape runs the generic kernels, where the
+    three branches write straight into the channel slices of the concat buffer (no torch.cat copy)."""
+    from .fused import mrf_fused_for
+    fz = None if force_generic else mrf_fused_for(blk)
+    if fz is not None and not (blk.training and blk.dropout.p > 0):
+        with torch.no_grad():
+            y = ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
+        return _track("mrf_block", y, x, *blk.parameters())
     with torch.no_grad():
         x = x if x.is_contiguous() else x.contiguous()
         B, C, T = x.shape

@@ -6,6 +6,7 @@ libmi355x_vocoder.so.  Inputs must live on the GPU: there is no CPU path.
 """
 from __future__ import annotations
 
+import weakref
 from ctypes import c_void_p
 from typing import Optional
 
@@ -54,8 +55,9 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 
 
 class _ParamCache:
-    """Casts of parameters to the activation dtype, keyed on (tensor identity, version) so that an
-    optimizer step (in-place update -> _version bump) invalidates them."""
+    """Casts of parameters to the activation dtype.  An entry is valid only for the very same tensor
+    object (weak reference - ids are recycled once a module is freed) at the same ``_version``, so an
+    optimizer step (in-place update -> version bump) or ``load_state_dict`` invalidates it."""
 
     def __init__(self):
         self._d = {}
@@ -67,10 +69,12 @@ class _ParamCache:
             return p.detach()
         key = (id(p), dtype)
         hit = self._d.get(key)
-        if hit is not None and hit[0] == p._version and hit[1].device == p.device:
-            return hit[1]
+        if hit is not None and hit[0]() is p and hit[1] == p._version and hit[2].device == p.device:
+            return hit[2]
         v = cast(p.detach(), dtype)
-        self._d[key] = (p._version, v)
+        if len(self._d) > 4096:  # drop entries whose parameter is gone
+            self._d = {k: e for k, e in self._d.items() if e[0]() is not None}
+        self._d[key] = (weakref.ref(p), p._version, v)
         return v
 
 

@@ -123,6 +123,34 @@ int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T, int dtype, void* 
 /* dtype conversion (fp32 <-> bf16/fp16) of n elements. */
 int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused MultiReceptiveFieldBlock, channels-last.   replaces grc_lora.py:32-68 (x3 branches) + :157-163 for the
+ * generator's instance: 64 -> 64 channels, three GRC_LoRA_Block(64, 20, 3, d_i, r) branches, Conv1d(60,64,1),
+ * GroupNorm(8,64), Dropout, + x.   x, out: [B][T][64] ("NTC").
+ *
+ * mv_mrf_params: raw parameter pointers of one block, all in `param_dtype`, index i = branch (conv_layers.i.*):
+ *   conv_w [20,16,3] conv_b [20] lora_A [64,r] lora_B [r,20] lora_scaling [1] proj_w [20,20(,1)] proj_b [20]
+ *   norm_w/norm_b [20] res_w [20,64(,1)] res_b [20]; fusion_w [64,60(,1)] fusion_b [64] norm2_w/norm2_b [64].
+ * mv_mrf_pack folds conv_g + LoRA + output_projection per branch (fp32) and writes MFMA-fragment-ordered weights
+ * for storage type `dtype` into `packed` (mv_mrf_packed_bytes(dtype) bytes, 16-byte aligned).  Re-run after every
+ * parameter update.  mv_mrf_block_fwd_cl runs the three passes (GN5 statistics, GN8 statistics, output);
+ * workspace: mv_mrf_workspace_bytes(B,T,dtype) bytes, fully rewritten by every call (no zero-fill needed).
+ * dropout_mask: optional uint8 keep-mask [B][T][64] (training), output scaled by mask_scale = 1/(1-p).
+ * dilations: host array of 3 ints (1..16, at most 7 distinct tap offsets).  x and out must not alias. */
+typedef struct mv_mrf_params {
+  const void* conv_w[3]; const void* conv_b[3]; const void* lora_A[3]; const void* lora_B[3];
+  const void* lora_scaling[3]; const void* proj_w[3]; const void* proj_b[3];
+  const void* norm_w[3]; const void* norm_b[3]; const void* res_w[3]; const void* res_b[3];
+  const void* fusion_w; const void* fusion_b; const void* norm2_w; const void* norm2_b;
+} mv_mrf_params;
+size_t mv_mrf_packed_bytes(int dtype);
+size_t mv_mrf_workspace_bytes(int B, int T, int dtype);
+int mv_mrf_pack(const mv_mrf_params* params, int param_dtype, const int* dilations, int lora_rank,
+                void* packed, int dtype, void* stream);
+int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int* dilations, void* workspace,
+                        const uint8_t* dropout_mask, float mask_scale, int B, int T, float eps, int dtype,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

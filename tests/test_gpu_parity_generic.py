@@ -228,3 +228,27 @@ def test_cpu_tensors_are_rejected(H):
     m = H.ODConv1d(8, 8, 3, padding=1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randn(1, 8, 16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,B", [(48, 2), (700, 3), (8192, 2)])
+def test_mrf_fused_vs_generic_and_golden(H, dtype, T, B):
+    """Fused channels-last MFMA MRF (csrc/mrf_fused.hip) against the golden (T=48) and against the generic
+    fp32 HIP path on longer ragged inputs (several tiles, partial last tile, multi-workgroup statistics)."""
+    from hifigan_modified import functional as Fn
+    g = load_golden("mrf_64_64")
+    m = load_sd(H.MultiReceptiveFieldBlock(64, 64), g).cuda().train(False)
+    if T == 48:
+        x = dev(g, "x.x", dtype)
+        ref = torch.from_numpy(g["y"])
+    else:
+        torch.manual_seed(3)
+        x32 = torch.randn(B, 64, T, device="cuda")
+        x = x32.to(dtype)
+        with torch.no_grad():
+            ref = Fn.mrf_block(x.float(), m, force_generic=True).cpu()
+    with torch.no_grad():
+        y = Fn.mrf_block(x, m)
+    err = O.rel_l2(y.float().cpu(), ref)
+    bound = {torch.float32: 2e-5, torch.float16: 1.5e-3, torch.bfloat16: 8e-3}[dtype]
+    assert err < bound, f"fused MRF {dtype} T={T}: rel-L2 {err:.3e}"
