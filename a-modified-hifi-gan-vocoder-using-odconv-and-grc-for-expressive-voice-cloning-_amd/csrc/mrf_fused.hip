@@ -44,7 +44,7 @@ static inline bool mrf_make_meta(const int* dil, MrfMeta* m) {
     if (n < MRF_MAXTAPS) offs[n++] = o; else n = MRF_MAXTAPS + 1;
   };
   add(0);
-  for (int i = 0; i < MRF_NBR; ++i) { if (dil[i] < 1 || dil[i] > 16) return false; add(-dil[i]); add(dil[i]); }
+  for (int i = 0; i < MRF_NBR; ++i) { if (dil[i] < 1 || dil[i] > 8) return false; add(-dil[i]); add(dil[i]); }
   if (n > 7) return false;
   for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (offs[j] < offs[i]) { int t = offs[i]; offs[i] = offs[j]; offs[j] = t; }
   m->ntaps = n; m->halo = 0;
@@ -153,20 +153,24 @@ __global__ __launch_bounds__(256) void mrf_pack_kernel(MrfRawParams p, MrfMeta m
 }
 
 // ------------------------------------------------------------------------------------------------ forward passes
+constexpr int MRF_HMAX = 8;   // largest dilation the fused kernel accepts (prefetch registers are sized for it)
+
 template <typename T, int NWAVES, int NTW, int PASS>
 __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                           const char* __restrict__ packed, MrfMeta meta,
                                                           const float* __restrict__ part5, float* __restrict__ part5_out,
                                                           const float* __restrict__ part8, float* __restrict__ part8_out,
                                                           const uint8_t* __restrict__ mask, float mask_scale,
-                                                          int Tn, int ntiles, float eps) {
+                                                          int Tn, int nwg, int nit, float eps) {
   using M = Mma<T>;
   using V = typename M::V;
   constexpr int ES = M::ES;
   constexpr int FS = M::NSETS * FRAG_BYTES;
-  constexpr int RS = MRF_C * ES + 16;                 // padded LDS row stride (bytes)
+  constexpr int RS = MRF_C * ES + (ES == 2 ? 32 : 16); // padded LDS row stride: conflict-free ds_read_b128 operand reads
   constexpr int WBYTES = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
-  constexpr int TW = NTW * 16;                        // time steps per wave
+  constexpr int TW = NTW * 16;                        // time steps per wave and iteration
+  constexpr int CH = MRF_C * ES / 16;                 // 16-byte chunks per row
+  constexpr int NLD = ((TW + 2 * MRF_HMAX) * CH + 63) / 64;   // prefetch registers (u32x4) per lane
 
   extern __shared__ __align__(16) char lds[];
   char* wl = lds;                                           // packed weights
@@ -178,37 +182,51 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y, tile = blockIdx.x;
+  const int b = blockIdx.y, wg = blockIdx.x;
   const int H = meta.halo;
   const int rows = TW + 2 * H;
   char* xw = xl + (size_t)wid * rows * RS;
-  const int t0 = (tile * NWAVES + wid) * TW;           // first time step of this wave
+  const T* xb = x + (size_t)b * Tn * MRF_C;
 
-  // ---- stage packed weights + tables (whole workgroup)
+  // ---- software pipeline: the NEXT tile's rows travel HBM -> registers while the current tile is computed
+  u32x4 pre[NLD];
+  auto tile_t0 = [&](int it) { return ((wg * nit + it) * NWAVES + wid) * TW; };
+  auto issue = [&](int it) {
+    const int t0 = tile_t0(it);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = lane + 64 * i;
+      const int r = idx / CH, ch = idx % CH;
+      const int t = t0 - H + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (idx < rows * CH && t >= 0 && t < Tn)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xb + (size_t)t * MRF_C) + ch * 16);
+      pre[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = lane + 64 * i;
+      const int r = idx / CH, ch = idx % CH;
+      if (idx < rows * CH) *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = pre[i];
+    }
+  };
+  issue(0);
+
+  // ---- stage packed weights + tables (whole workgroup, once)
   {
     const int n16 = (WBYTES + MRF_TAB_FLOATS * 4) / 16;
     const u32x4* src = reinterpret_cast<const u32x4*>(packed);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
     for (int i = tid; i < n16; i += NWAVES * 64) dst[i] = src[i];
   }
-  // ---- stage this wave's x tile: rows t0-H .. t0+TW+H-1, 64 channels, zero outside [0,Tn)
-  {
-    constexpr int CH = MRF_C * ES / 16;                  // 16-byte chunks per row
-    const T* xb = x + (size_t)b * Tn * MRF_C;
-    for (int i = lane; i < rows * CH; i += 64) {
-      const int r = i / CH, ch = i % CH;
-      const int t = t0 - H + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (t >= 0 && t < Tn) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xb + (size_t)t * MRF_C) + ch * 16);
-      *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = v;
-    }
-  }
   // ---- GroupNorm statistics from the previous passes' partial sums (fixed summation order)
   if (PASS >= 2 && tid < 16) {
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < ntiles; ++i) {
-      s1 += part5[((size_t)(b * ntiles + i) * 16 + tid) * 2];
-      s2 += part5[((size_t)(b * ntiles + i) * 16 + tid) * 2 + 1];
+    for (int i = 0; i < nwg; ++i) {
+      s1 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2];
+      s2 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2 + 1];
     }
     const float n = 4.f * (float)Tn, mu = s1 / n;
     const float var = fmaxf(s2 / n - mu * mu, 0.f);
@@ -218,9 +236,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   if (PASS >= 3 && tid >= 64 && tid < 72) {
     const int q = tid - 64;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < ntiles; ++i) {
-      s1 += part8[((size_t)(b * ntiles + i) * 8 + q) * 2];
-      s2 += part8[((size_t)(b * ntiles + i) * 8 + q) * 2 + 1];
+    for (int i = 0; i < nwg; ++i) {
+      s1 += part8[((size_t)(b * nwg + i) * 8 + q) * 2];
+      s2 += part8[((size_t)(b * nwg + i) * 8 + q) * 2 + 1];
     }
     const float n = 8.f * (float)Tn, mu = s1 / n;
     const float var = fmaxf(s2 / n - mu * mu, 0.f);
@@ -231,47 +249,161 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
   const float* b_conv = tab, *b_res = tab + 64, *b_fus = tab + 128;
   const float* g5 = tab + 192, *be5 = tab + 256, *g8 = tab + 320, *be8 = tab + 384;
-
-  // ---- stage 1: v[cc][t] = b_eff + sum_{tap,c} W_eff[cc][tap][c] x[t+off(tap)][c]
-  f32x4 v[4][NTW];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const f32x4 bi = *reinterpret_cast<const f32x4*>(b_conv + 16 * m + 4 * g);
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) v[m][n] = bi;
-  }
   const char* xcol = xw + (size_t)(col + H) * RS + 8 * g * ES;   // this lane's B-operand base
-  for (int tap = 0; tap < meta.ntaps; ++tap) {
-    const int off = meta.tap_off[tap];
+  T* ob = out + (size_t)b * Tn * MRF_C;
+
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // statistics partials (passes 1, 2)
+
+  for (int it = 0; it < nit; ++it) {
+    const int t0 = tile_t0(it);
+    commit();                       // this tile: registers -> this wave's private LDS region
+    if (it + 1 < nit) issue(it + 1);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- stage 1: v[cc][t] = b_eff + sum_{tap,c} W_eff[cc][tap][c] x[t+off(tap)][c]
+    f32x4 v[4][NTW];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(b_conv + 16 * m + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) v[m][n] = bi;
+    }
+    for (int tap = 0; tap < meta.ntaps; ++tap) {
+      const int off = meta.tap_off[tap];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        V bf[NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16 + off) * RS + ks * 32 * ES);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int fo = meta.frag_of[m][tap];
+          if (fo >= 0) {
+            const V a = M::load_a(wl + (size_t)(fo * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
+          }
+        }
+      }
+    }
+
+    if (PASS == 1) {
+      // partial sums of v per GN(5,20) group: concat rows 16m+4g..+3 are exactly group 4m+g
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const bool ok = (t0 + n * 16 + col) < Tn;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float q = ok ? v[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
+        }
+      continue;
+    }
+
+    // ---- stage 2: c = SiLU(GN5(v)) + b_res + W_res x : activate in place, then let the residual 1x1 accumulate
+    //      straight onto the activated values (no second accumulator set)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const float mu = st5[(4 * m + g) * 2], rs = st5[(4 * m + g) * 2 + 1];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(g5 + 16 * m + 4 * g);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(be5 + 16 * m + 4 * g);
+      const f32x4 br = *reinterpret_cast<const f32x4*>(b_res + 16 * m + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sc = rs * ga[r], sh = be[r] - mu * sc;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const float w = v[m][n][r] * sc + sh;
+          v[m][n][r] = w * __builtin_amdgcn_rcpf(1.f + __expf(-w)) + br[r];   // SiLU (v_exp + v_rcp, 1 ulp)
+        }
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       V bf[NTW];
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16 + off) * RS + ks * 32 * ES);
+      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16) * RS + ks * 32 * ES);
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const int fo = meta.frag_of[m][tap];
-        if (fo >= 0) {
-          const V a = M::load_a(wl + (size_t)(fo * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
 #pragma unroll
-          for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
-        }
+        for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
       }
     }
+
+    // ---- stage 3: f[co][t] = b_fus + sum_cc W_fus[co][cc] c[cc][t]   (c fed straight from the accumulators)
+    f32x4 f[4][NTW];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(b_fus + 16 * m + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) f[m][n] = bi;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      V cb[NTW];
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) cb[n] = M::from_acc(v[2 * s][n], v[2 * s + 1][n]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(a, cb[n], f[m][n]);
+      }
+    }
+
+    if (PASS == 2) {
+      // partial sums of f per GN(8,64) group: rows 16m+4g+r -> group 2m + (g>>1)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const bool ok = (t0 + n * 16 + col) < Tn;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float q = ok ? f[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
+        }
+      continue;
+    }
+
+    // ---- stage 4 (pass 3): out = GN8(f) * keep/(1-p) + x, written IN PLACE over this wave's x tile, then streamed
+    //      to HBM as whole 128/256-byte rows (16 B per lane, 1 KB per wave instruction)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int q = 2 * m + (g >> 1);
+      const float mu = st8[q * 2], rs = st8[q * 2 + 1];
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(g8 + 16 * m + 4 * g);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(be8 + 16 * m + 4 * g);
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        const int t = t0 + n * 16 + col;
+        char* cell = xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES;
+        float xr[4], o[4];
+        M::load4(cell, xr);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sc = rs * ga[r];
+          float w = f[m][n][r] * sc + (be[r] - mu * sc);
+          if (mask) w = (t < Tn && mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r]) ? w * mask_scale : 0.f;
+          o[r] = w + xr[r];
+        }
+        M::store4(cell, o);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < (TW * CH) / 64; ++i) {
+      const int idx = lane + 64 * i;
+      const int r = idx / CH, ch = idx % CH;
+      const int t = t0 + r;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(xw + (size_t)(r + H) * RS + ch * 16);
+      if (t < Tn) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + ch * 16) = val;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 
   if (PASS == 1) {
-    // partial sums of v per GN(5,20) group: concat rows 16m+4g..+3 are exactly group 4m+g
-    float s1[4], s2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      s1[m] = 0.f; s2[m] = 0.f;
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        const bool ok = (t0 + n * 16 + col) < Tn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float q = ok ? v[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
-      }
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) { s1[m] += __shfl_xor(s1[m], o, 64); s2[m] += __shfl_xor(s2[m], o, 64); }
     }
@@ -283,82 +415,12 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     if (tid < 32) {
       float a = 0.f;
       for (int w = 0; w < NWAVES; ++w) a += red[w * 32 + tid];
-      part5_out[(size_t)(b * ntiles + tile) * 32 + tid] = a;
-    }
-    return;
-  }
-
-  // ---- stage 2: a = SiLU(GN5(v)) ; r = b_res + W_res x ; c = a + r   (c overwrites v)
-  {
-    f32x4 rr[4][NTW];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const f32x4 bi = *reinterpret_cast<const f32x4*>(b_res + 16 * m + 4 * g);
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) rr[m][n] = bi;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      V bf[NTW];
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16) * RS + ks * 32 * ES);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) rr[m][n] = M::mma(a, bf[n], rr[m][n]);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float mu = st5[(4 * m + g) * 2], rs = st5[(4 * m + g) * 2 + 1];
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(g5 + 16 * m + 4 * g);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(be5 + 16 * m + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sc = rs * ga[r], sh = be[r] - mu * sc;
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-          const float w = v[m][n][r] * sc + sh;
-          v[m][n][r] = w / (1.f + __expf(-w)) + rr[m][n][r];
-        }
-      }
+      part5_out[(size_t)(b * nwg + wg) * 32 + tid] = a;
     }
   }
-
-  // ---- stage 3: f[co][t] = b_fus + sum_cc W_fus[co][cc] c[cc][t]   (c fed straight from the accumulators)
-  f32x4 f[4][NTW];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const f32x4 bi = *reinterpret_cast<const f32x4*>(b_fus + 16 * m + 4 * g);
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) f[m][n] = bi;
-  }
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    V cb[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) cb[n] = M::from_acc(v[2 * s][n], v[2 * s + 1][n]);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(a, cb[n], f[m][n]);
-    }
-  }
-
   if (PASS == 2) {
-    // partial sums of f per GN(8,64) group: rows 16m+4g+r -> group 2m + (g>>1)
-    float s1[4], s2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      s1[m] = 0.f; s2[m] = 0.f;
-#pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        const bool ok = (t0 + n * 16 + col) < Tn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float q = ok ? f[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
-      }
 #pragma unroll
       for (int o = 1; o <= 16; o <<= 1) { s1[m] += __shfl_xor(s1[m], o, 64); s2[m] += __shfl_xor(s2[m], o, 64); }
     }
@@ -370,36 +432,18 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     if (tid < 16) {
       float a = 0.f;
       for (int w = 0; w < NWAVES; ++w) a += red[w * 16 + tid];
-      part8_out[(size_t)(b * ntiles + tile) * 16 + tid] = a;
+      part8_out[(size_t)(b * nwg + wg) * 16 + tid] = a;
     }
-    return;
   }
+}
 
-  // ---- stage 4 (pass 3): out = GN8(f) * keep/(1-p) + x
-  T* ob = out + (size_t)b * Tn * MRF_C;
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int q = 2 * m + (g >> 1);
-    const float mu = st8[q * 2], rs = st8[q * 2 + 1];
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(g8 + 16 * m + 4 * g);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(be8 + 16 * m + 4 * g);
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-      const int t = t0 + n * 16 + col;
-      if (t < Tn) {
-        float xr[4], o[4];
-        M::load4(xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES, xr);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = rs * ga[r];
-          float w = f[m][n][r] * sc + (be[r] - mu * sc);
-          if (mask) w = mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r] ? w * mask_scale : 0.f;
-          o[r] = w + xr[r];
-        }
-        M::store4(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + (16 * m + 4 * g) * ES, o);
-      }
-    }
-  }
+// workgroups per sample and tiles per wave: aim at one persistent workgroup per CU when the batch allows it
+static inline void mrf_geometry(int B, int Tn, int tile_t, int* nwg, int* nit) {
+  const int ntiles = cdiv(Tn, tile_t);
+  int it = 1;
+  while (it < 4 && (long)B * cdiv(ntiles, it) > 256 && cdiv(ntiles, it * 2) >= 1 && ntiles >= it * 2) it *= 2;
+  *nit = it;
+  *nwg = cdiv(ntiles, it);
 }
 
 template <typename T, int NWAVES, int NTW>
@@ -407,15 +451,15 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
                       const uint8_t* mask, float mask_scale, int B, int Tn, float eps, hipStream_t stream) {
   using M = Mma<T>;
   constexpr int FS = M::NSETS * FRAG_BYTES;
-  constexpr int RS = MRF_C * M::ES + 16;
-  const int tile_t = NWAVES * NTW * 16;
-  const int ntiles = cdiv(Tn, tile_t);
+  constexpr int RS = MRF_C * M::ES + (M::ES == 2 ? 32 : 16);
+  int nwg, nit;
+  mrf_geometry(B, Tn, NWAVES * NTW * 16, &nwg, &nit);
   const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
                      (size_t)NWAVES * 32 * 4 + (size_t)NWAVES * (NTW * 16 + 2 * meta.halo) * RS;
-  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024 || meta.halo > MRF_HMAX) return MV_ERR_UNSUPPORTED;
   float* part5 = ws;
-  float* part8 = ws + (size_t)B * ntiles * 32;
-  dim3 grid(ntiles, B), block(NWAVES * 64);
+  float* part8 = ws + (size_t)B * nwg * 32;
+  dim3 grid(nwg, B), block(NWAVES * 64);
   auto k1 = mrf_kernel<T, NWAVES, NTW, 1>;
   auto k2 = mrf_kernel<T, NWAVES, NTW, 2>;
   auto k3 = mrf_kernel<T, NWAVES, NTW, 3>;
@@ -427,11 +471,11 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
     lds_set = lds;
   }
   hipLaunchKernelGGL(k1, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, nullptr, part5,
-                     nullptr, nullptr, nullptr, 1.f, Tn, ntiles, eps);
+                     nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps);
   hipLaunchKernelGGL(k2, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     nullptr, part8, nullptr, 1.f, Tn, ntiles, eps);
+                     nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps);
   hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     part8, nullptr, mask, mask_scale, Tn, ntiles, eps);
+                     part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps);
   return MV_OK;
 }
 
@@ -452,7 +496,7 @@ extern "C" size_t mv_mrf_packed_bytes(int dtype) {
 static inline int mrf_tile_t(int dtype) { return dtype == MV_F32 ? 4 * 2 * 16 : 8 * 4 * 16; }
 
 extern "C" size_t mv_mrf_workspace_bytes(int B, int T_, int dtype) {
-  const int ntiles = cdiv(T_, mrf_tile_t(dtype));
+  const int ntiles = cdiv(T_, mrf_tile_t(dtype));   // upper bound on workgroups per sample
   return (size_t)B * ntiles * (32 + 16) * sizeof(float);
 }
 

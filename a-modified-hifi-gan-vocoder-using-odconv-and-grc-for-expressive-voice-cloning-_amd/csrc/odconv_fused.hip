@@ -1,0 +1,445 @@
+// Channels-last ODConv1d / ODConvTranspose1d on MFMA: attention -> kernel aggregation -> convolution
+// (+ bias, FiLM, LeakyReLU, next-layer pooling) in ONE launch.
+//   reference arithmetic: hifigan_modified/odconv.py:73-108 (ODConv1d) and :172-205 (ODConvTranspose1d);
+//                         FiLM epilogue: grc_lora.py:111-129; LeakyReLU(0.1): SURVEY.md §A item 2.
+//
+// Formulation.  Per sample b the layer is a GEMM  D[row][q] = sum_k Wb[row][k] X[k][q]  with the per-sample kernel
+// Wb = sum_kb alpha[b,kb] W[kb] (K banks) formed ON THE FLY in registers while the A operand is loaded:
+//   regular conv (stride 1):   row = o,        k = (j, c),   X[(j,c)][t] = x[t - pad + j*dil][c],  y[t][o]
+//   transposed conv:           row = (r, o),   k = (m, c),   X[(m,c)][q] = x[q - m][c],            y[s*q + r - pad][o]
+//     with kernel tap j = r + m*s  (r = output phase, m = 0..ks/s-1): every output sample is produced exactly once,
+//     there is no overlap-add and the output rows of one q are s*Cout CONTIGUOUS channels-last elements.
+// alpha itself is computed in the prologue from the pooled channel sums that the PRODUCING kernel accumulated in its
+// epilogue (pooled_out), so the "mean over all T" dependency of odconv.py:37,85 costs no extra pass over x.
+//
+// Tiling: workgroup = 4 waves; wave w owns MW 16-row M-tiles; the workgroup covers S samples x NB 16-column N-tiles.
+// The x tiles of the S samples live in LDS (row stride padded by 16 B); bank weights stream from L2 in packed
+// A-fragment order (one coalesced 1 KB load per bank per fragment) and are reused for the S samples.
+#include "mfma.h"
+
+namespace mv {
+
+constexpr int OD_MAXK = 8;
+
+struct OdP {
+  int B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act;
+  float slope;
+  int M;          // GEMM rows: Cout (conv) or stride*Cout (transposed)
+  int ntaps;      // ks (conv) or ks/stride (transposed)
+  int nchunks;    // ntaps*Cin/8 valid 8-channel chunks along k
+  int ksteps;     // ceil(nchunks/4)
+  int nq;         // GEMM columns per sample: Tout (conv) or Tin + ntaps - 1 (transposed)
+  int shift_lo;   // lowest input-row shift: -pad (conv) or -(ntaps-1) (transposed)
+  int nrows;      // LDS rows per sample tile
+  int film_F;
+};
+
+template <typename T> struct WLoad;   // this lane's 8 packed weights -> fp32
+template <> struct WLoad<bf16> {
+  static constexpr int BYTES = 16;
+  struct R { u32x4 u; };
+  static __device__ __forceinline__ R load(const char* p) { R r; r.u = *reinterpret_cast<const u32x4*>(p); return r; }
+  static __device__ __forceinline__ void fma8(const R& r, float a, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] += a * bf16_lo(r.u[i]); f[2 * i + 1] += a * bf16_hi(r.u[i]); }
+  }
+};
+template <> struct WLoad<f16> {
+  static constexpr int BYTES = 16;
+  struct R { f16x8_t h; };
+  static __device__ __forceinline__ R load(const char* p) { R r; r.h = *reinterpret_cast<const f16x8_t*>(p); return r; }
+  static __device__ __forceinline__ void fma8(const R& r, float a, float* f) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] += a * (float)r.h[i];
+  }
+};
+template <> struct WLoad<float> {
+  static constexpr int BYTES = 32;
+  struct R { f32x4 a, b; };
+  static __device__ __forceinline__ R load(const char* p) {
+    R r; r.a = reinterpret_cast<const f32x4*>(p)[0]; r.b = reinterpret_cast<const f32x4*>(p)[1]; return r;
+  }
+  static __device__ __forceinline__ void fma8(const R& r, float a, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[i] += a * r.a[i]; f[4 + i] += a * r.b[i]; }
+  }
+};
+
+template <typename T> __device__ __forceinline__ typename Mma<T>::V make_a(const float* f);
+template <> __device__ __forceinline__ Mma<bf16>::V make_a<bf16>(const float* f) {
+  u32x4 u = {pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7])};
+  Mma<bf16>::V r; r.v = __builtin_bit_cast(bf16x8_t, u); return r;
+}
+template <> __device__ __forceinline__ Mma<f16>::V make_a<f16>(const float* f) {
+  u32x4 u = {pack_f16(f[0], f[1]), pack_f16(f[2], f[3]), pack_f16(f[4], f[5]), pack_f16(f[6], f[7])};
+  Mma<f16>::V r; r.v = __builtin_bit_cast(f16x8_t, u); return r;
+}
+template <> __device__ __forceinline__ Mma<float>::V make_a<float>(const float* f) { return Mma<float>::split(f); }
+
+// ------------------------------------------------------------------------------------------------ pack
+// packed[kb][mtile][kstep][lane][8] : element j of lane = W row (16*mtile + lane&15), k-chunk (4*kstep + lane>>4), k = 8*chunk + j
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void odconv_pack_kernel(const P* __restrict__ w, T* __restrict__ out, OdP p) {
+  const long per_bank = (long)(p.M / 16) * p.ksteps * 512;
+  const long total = per_bank * p.K;
+  const int cpc = p.Cin / 8;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = idx % 8, lane = (idx / 8) % 64;
+    const long fr = idx / 512;
+    const int kstep = fr % p.ksteps;
+    const int mt = (fr / p.ksteps) % (p.M / 16);
+    const int kb = fr / ((long)p.ksteps * (p.M / 16));
+    const int row = 16 * mt + (lane & 15), chunk = 4 * kstep + (lane >> 4);
+    float v = 0.f;
+    if (chunk < p.nchunks) {
+      const int tap = chunk / cpc, c = 8 * (chunk % cpc) + j;
+      if (p.transposed) {
+        const int r = row / p.Cout, o = row % p.Cout, jj = r + tap * p.stride;
+        v = ld<P>(w + (((long)kb * p.Cin + c) * p.Cout + o) * p.ks + jj);       // [K][Cin][Cout][ks]
+      } else {
+        v = ld<P>(w + (((long)kb * p.Cout + row) * p.Cin + c) * p.ks + tap);    // [K][Cout][Cin][ks]
+      }
+    }
+    st<T>(out + idx, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <typename T, int S, int MW, int NB, bool PF>
+__global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                        const T* __restrict__ bias, const float* __restrict__ alpha_in,
+                                                        const float* __restrict__ pooled_in, const T* __restrict__ att_w,
+                                                        const T* __restrict__ att_b, const T* __restrict__ film,
+                                                        T* __restrict__ y, float* __restrict__ pooled_out, OdP p) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  using WL = WLoad<T>;
+  constexpr int ES = M::ES;
+  extern __shared__ __align__(16) char lds[];
+  float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha
+  char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
+  const int RS = p.Cin * ES + 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * NB * 16;
+  const int mt0 = (blockIdx.y * 4 + wid) * MW;                 // first M-tile of this wave
+  const int b0 = blockIdx.z * S;
+  const int n_mt = p.M / 16;
+
+  // ---- alpha for the S samples: given, or softmax(Wa . pooled/Tin + ba) (odconv.py:36-40)
+  if (alpha_in) {
+    if (tid < S * p.K) {
+      const int s = tid / p.K, kb = tid % p.K;
+      alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
+    }
+  } else {
+    // wave w computes logits of (s,kb) pairs w, w+4, ...
+    for (int pr = wid; pr < S * p.K; pr += 4) {
+      const int s = pr / p.K, kb = pr % p.K;
+      float acc = 0.f;
+      if (b0 + s < p.B)
+        for (int c = lane; c < p.Cin; c += 64) acc += ld<T>(att_w + (long)kb * p.Cin + c) * pooled_in[(long)(b0 + s) * p.Cin + c];
+      acc = wave_sum(acc);
+      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+    }
+    __syncthreads();
+    if (tid < S) {
+      float m = -INFINITY, den = 0.f;
+      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
+      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
+      for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
+    }
+  }
+  // ---- stage x tiles: input rows q0+shift_lo .. +nrows-1 of every sample, zero outside [0,Tin)
+  {
+    const int cpr = p.Cin * ES / 16;
+    const int per = p.nrows * cpr;
+    for (int i = tid; i < S * per; i += 256) {
+      const int s = i / per, rem = i % per;
+      const int r = rem / cpr, ch = rem % cpr;
+      const int tin = q0 + p.shift_lo + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (b0 + s < p.B && tin >= 0 && tin < p.Tin)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
+      *reinterpret_cast<u32x4*>(xl + ((long)s * p.nrows + r) * RS + ch * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  float al[S][OD_MAXK];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int kb = 0; kb < OD_MAXK; ++kb) al[s][kb] = kb < p.K ? alds[s * OD_MAXK + kb] : 0.f;
+
+  f32x4 acc[S][MW][NB];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[s][mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cpc = p.Cin / 8;
+  const long bank_stride = (long)n_mt * p.ksteps * 512 * ES;     // bytes between banks
+  const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 8 * ES;
+  auto wload = [&](int kstep, typename WL::R (&dst)[MW][OD_MAXK]) {
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);   // clamp: out-of-range tiles compute garbage that is never stored
+      const char* wbase = wlane + ((long)mt * p.ksteps + kstep) * 512 * ES;
+#pragma unroll
+      for (int kb = 0; kb < OD_MAXK; ++kb)
+        if (kb < p.K) dst[mw][kb] = WL::load(wbase + kb * bank_stride);
+    }
+  };
+  typename WL::R wr[MW][OD_MAXK];
+  wload(0, wr);
+  int tap = 0, c8 = g;                                           // this lane's chunk (4*kstep + g) as (tap, c8)
+  while (c8 >= cpc) { c8 -= cpc; ++tap; }
+  for (int kstep = 0; kstep < p.ksteps; ++kstep) {
+    typename WL::R wn[MW][OD_MAXK];
+    if (PF && kstep + 1 < p.ksteps) wload(kstep + 1, wn);        // next fragments travel L2 -> registers under this step's math
+    // per-sample kernels for this k-step: sum_kb alpha[s,kb] * W[kb]  (fp32, then one rounding to the operand type)
+    V afr[S][MW];
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < OD_MAXK; ++kb)
+          if (kb < p.K) WL::fma8(wr[mw][kb], al[s][kb], f);
+        afr[s][mw] = make_a<T>(f);
+      }
+    // B operands: x[q + shift(tap)][8*c8 ..], loaded just in time
+    const bool kvalid = (4 * kstep + g) < p.nchunks;
+    const int shift = p.transposed ? -tap : (tap * p.dil - p.pad);
+    const int rbase = kvalid ? (shift - p.shift_lo + col) : col;
+    const int coff = kvalid ? c8 * 8 * ES : 0;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const V bf = M::load_b(xl + ((long)s * p.nrows + rbase + n * 16) * RS + coff);
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw) acc[s][mw][n] = M::mma(afr[s][mw], bf, acc[s][mw][n]);
+      }
+    if (PF) {
+      if (kstep + 1 < p.ksteps) {
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+          for (int kb = 0; kb < OD_MAXK; ++kb)
+            if (kb < p.K) wr[mw][kb] = wn[mw][kb];
+      }
+    } else if (kstep + 1 < p.ksteps) {
+      wload(kstep + 1, wr);
+    }
+    c8 += 4;
+    while (c8 >= cpc) { c8 -= cpc; ++tap; }
+  }
+
+  // ---- epilogue: bias, FiLM, activation -> LDS tile [s][q][rows of this workgroup] -> whole-row 16-byte stores
+  __syncthreads();                                   // every wave is done with the x tiles: reuse the region
+  constexpr int RW = 4 * MW * 16;                    // GEMM rows covered by this workgroup
+  constexpr int ORS = RW * ES + 16;                  // staged row stride (bytes)
+  char* ol = xl;
+  const int R0 = blockIdx.y * RW;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int b = b0 + s;
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
+      float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mt < n_mt && b < p.B) {
+        const int row = 16 * mt + 4 * g;
+        const int r = p.transposed ? row / p.Cout : 0;
+        const int o = p.transposed ? row % p.Cout : row;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias)
+          for (int kb = 0; kb < p.K; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] += al[s][kb] * ld<T>(bias + (long)kb * p.Cout + o + i);
+        if (film)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (o + i < p.film_F) {
+              gam[i] = ld<T>(film + (long)b * 2 * p.film_F + o + i);
+              bet[i] = ld<T>(film + (long)b * 2 * p.film_F + p.film_F + o + i);
+            }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int q = q0 + n * 16 + col;
+          const int u = p.transposed ? q * p.stride + r - p.pad : q;
+          const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+          float ov[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float vv = (acc[s][mw][n][i] + bv[i]);
+            if (film) vv = M::round_store(vv) * gam[i] + bet[i];   // the reference stores the conv output before FiLM
+            vv = apply_act(vv, p.act, p.slope);
+            ov[i] = vv;
+            if (ok) rowsum[i] += M::round_store(vv);
+          }
+          M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+        }
+      }
+      if (pooled_out) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = rowsum[i];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+          rowsum[i] = v;
+        }
+        if (col == 0 && mt < n_mt && b < p.B) {
+          const int row = 16 * mt + 4 * g;
+          const int o = p.transposed ? row % p.Cout : row;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int EPC = 16 / ES;                     // elements per 16-byte chunk
+    constexpr int CPR = RW / EPC;                    // chunks per staged row
+    const int total = S * NB * 16 * CPR;
+    for (int i = tid; i < total; i += 256) {
+      const int ch = i % CPR, qi = (i / CPR) % (NB * 16), s = i / (CPR * NB * 16);
+      const int b = b0 + s, q = q0 + qi, row = R0 + ch * EPC;
+      if (b >= p.B || q >= p.nq || row >= p.M) continue;
+      const int r = p.transposed ? row / p.Cout : 0;
+      const int o = p.transposed ? row % p.Cout : row;
+      const int u = p.transposed ? q * p.stride + r - p.pad : q;
+      if (u < 0 || u >= p.Tout) continue;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)(s * NB * 16 + qi)) * ORS + ch * 16);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
+    }
+  }
+}
+
+template <typename T, int S, int MW, int NB>
+static int od_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
+                     const void* att_w, const void* att_b, const void* film, void* y, float* pooled_out, OdP p,
+                     hipStream_t stream) {
+  using M = Mma<T>;
+  p.nrows = NB * 16 + (p.ntaps - 1) * (p.transposed ? 1 : p.dil);
+  const size_t xbytes = (size_t)S * p.nrows * (p.Cin * M::ES + 16);
+  const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
+  const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = odconv_cl_kernel<T, S, MW, NB, (M::ES == 2)>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  dim3 grid(cdiv(p.nq, NB * 16), cdiv(p.M / 16, 4 * MW), cdiv(p.B, S));
+  if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
+                     (const T*)att_w, (const T*)att_b, (const T*)film, (T*)y, pooled_out, p);
+  return MV_OK;
+}
+
+static bool od_make(OdP* p, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                    int transposed, int K, int act, float slope, int film_F) {
+  if (B <= 0 || Cin <= 0 || Cin % 8 || Cout <= 0 || Cout % 8 || Tin <= 0 || ks <= 0 || K < 1 || K > OD_MAXK) return false;
+  p->B = B; p->Cin = Cin; p->Tin = Tin; p->Cout = Cout; p->Tout = Tout; p->ks = ks; p->stride = stride; p->pad = pad;
+  p->dil = dil; p->transposed = transposed; p->K = K; p->act = act; p->slope = slope; p->film_F = film_F;
+  if (transposed) {
+    if (dil != 1 || stride < 1 || ks % stride || pad < 0) return false;
+    p->ntaps = ks / stride;
+    p->M = stride * Cout;
+    const int full = (Tin - 1) * stride - 2 * pad + ks;
+    if (Tout < full || Tout >= full + stride) return false;
+    p->nq = Tin + p->ntaps - 1 + (Tout > full ? 1 : 0);   // output_padding rows come from one more (zero-input) column
+    p->shift_lo = -(p->ntaps - 1);
+  } else {
+    if (stride != 1 || dil < 1 || pad < 0) return false;
+    if (Tout != Tin + 2 * pad - dil * (ks - 1)) return false;
+    p->ntaps = ks;
+    p->M = Cout;
+    p->nq = Tout;
+    p->shift_lo = -pad;
+  }
+  if (p->M % 16) return false;
+  p->nchunks = p->ntaps * (Cin / 8);
+  p->ksteps = cdiv(p->nchunks, 4);
+  p->nrows = 0;
+  return true;
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" size_t mv_odconv_cl_packed_bytes(int Cin, int Cout, int ks, int stride, int transposed, int K, int dtype) {
+  OdP p;
+  const int Tin = 4;
+  const int Tout = transposed ? (Tin - 1) * stride + ks : Tin;   // any consistent length: only M/ksteps matter here
+  if (!od_make(&p, 1, Cin, Tin, Cout, Tout, ks, stride, transposed ? 0 : 0, 1, transposed, K, 0, 0.f, 0)) {
+    // regular conv with pad 0 needs Tout = Tin - (ks-1): retry with a consistent pair
+    if (transposed || !od_make(&p, 1, Cin, ks + 3, Cout, 4, ks, 1, 0, 1, 0, K, 0, 0.f, 0)) return 0;
+  }
+  const size_t es = dtype == MV_F32 ? 4 : 2;
+  return (size_t)K * (p.M / 16) * p.ksteps * 512 * es;
+}
+
+extern "C" int mv_odconv_cl_pack(const void* kernels, int param_dtype, void* packed, int Cin, int Cout, int ks,
+                                 int stride, int transposed, int K, int dtype, void* stream) {
+  MV_CHECK_ARG(kernels && packed);
+  OdP p;
+  const int Tin = ks + 3;
+  const int Tout = transposed ? (Tin - 1) * stride + ks : Tin - (ks - 1);
+  if (!od_make(&p, 1, Cin, Tin, Cout, Tout, ks, stride, 0, 1, transposed, K, 0, 0.f, 0)) return MV_ERR_UNSUPPORTED;
+  const long total = (long)K * (p.M / 16) * p.ksteps * 512;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  MV_DISPATCH(dtype, {
+    switch (param_dtype) {
+      case MV_F32: hipLaunchKernelGGL((odconv_pack_kernel<T, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)kernels, (T*)packed, p); break;
+      case MV_BF16: hipLaunchKernelGGL((odconv_pack_kernel<T, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)kernels, (T*)packed, p); break;
+      case MV_F16: hipLaunchKernelGGL((odconv_pack_kernel<T, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)kernels, (T*)packed, p); break;
+      default: return MV_ERR_DTYPE;
+    }
+  });
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha,
+                                const float* pooled_in, const void* att_w, const void* att_b, const void* film_proj,
+                                int film_F, void* y, float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout,
+                                int ks, int stride, int pad, int dil, int transposed, int K, int act, float slope,
+                                int dtype, void* stream) {
+  MV_CHECK_ARG(x && packed && y && (alpha || (pooled_in && att_w)));
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+  OdP p;
+  if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, film_proj ? film_F : 0))
+    return MV_ERR_UNSUPPORTED;
+  const int ntiles = cdiv(p.nq, 16);
+  const long wbytes = (long)K * p.M * p.ksteps * 32 * (dtype == MV_F32 ? 4 : 2);
+  int rc = MV_ERR_DTYPE;
+  hipStream_t st_ = (hipStream_t)stream;
+#define OD_GO(S_, MW_, NB_) rc = od_launch<T, S_, MW_, NB_>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_)
+  MV_DISPATCH(dtype, {
+    if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler): share bank loads over 2 samples
+      OD_GO(2, 1, 3);
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
+    } else if (wbytes > (1 << 20)) {         // big kernels, medium sequences: 144-column blocks amortise the aggregation
+      OD_GO(1, 2, 9);
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
+    } else {                                 // small kernels, long sequences: HBM-streaming regime
+      OD_GO(1, 2, 8);
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
+    }
+  });
+#undef OD_GO
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

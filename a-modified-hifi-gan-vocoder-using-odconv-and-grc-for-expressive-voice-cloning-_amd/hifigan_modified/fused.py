@@ -39,7 +39,7 @@ class MrfFused:
                 return False
         offs = {0}
         for d in blk.dilations:
-            if not 1 <= d <= 16:
+            if not 1 <= d <= 8:
                 return False
             offs |= {d, -d}
         return len(offs) <= 7
@@ -103,4 +103,154 @@ def mrf_fused_for(blk):
     if f is None:
         f = MrfFused(blk) if MrfFused.supported(blk) else False
         object.__setattr__(blk, "_mv_fused", f)
+    return f or None
+
+
+class OdconvFused:
+    """Packed-bank cache + launcher of mv_odconv_cl_fwd for one ODConv1d / ODConvTranspose1d."""
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.transposed = bool(getattr(mod, "_transposed", False))
+        self._packed = {}
+
+    def geometry(self):
+        m = self.mod
+        return (m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, m.dilation, int(self.transposed), m.K)
+
+    def supported(self) -> bool:
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        if cin % 8 or cout % 8 or K > 8:
+            return False
+        rows = stride * cout if tr else cout
+        if rows % 16:
+            return False
+        if tr:
+            return dil == 1 and ks % stride == 0
+        return stride == 1
+
+    def packed(self, dtype, device):
+        w = self.mod.kernels
+        ver = (w._version, w.data_ptr())
+        hit = self._packed.get(dtype)
+        if hit is not None and hit[0] == ver and hit[1].device == device:
+            return hit[1]
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        nbytes = N.lib().mv_odconv_cl_packed_bytes(cin, cout, ks, stride, tr, K, ops._DT[dtype])
+        if nbytes == 0:
+            raise RuntimeError("odconv_cl: unsupported geometry")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        wd = w.detach()
+        wd = wd if wd.is_contiguous() else wd.contiguous()
+        N.call("mv_odconv_cl_pack", c_void_p(wd.data_ptr()), ops._DT[wd.dtype], c_void_p(buf.data_ptr()), cin, cout, ks,
+               stride, tr, K, ops._DT[dtype], ops._stream())
+        self._packed[dtype] = (ver, buf)
+        return buf
+
+    def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
+                   act=N.ACT_NONE, slope=0.1):
+        m = self.mod
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        B, Tin, C = x_cl.shape
+        assert C == cin and x_cl.is_contiguous()
+        if tr:
+            Tout = (Tin - 1) * stride - 2 * pad + ks + m.output_padding
+        else:
+            Tout = Tin + 2 * pad - dil * (ks - 1)
+        y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=x_cl.dtype)
+        att = m.kernel_attention[1]
+        P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        N.call("mv_odconv_cl_fwd", P(x_cl), P(self.packed(x_cl.dtype, x_cl.device)), P(cache.get(m.bias, x_cl.dtype)),
+               P(alpha), P(pooled_in), P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)),
+               P(film_proj), int(film_F), P(y), P(pooled_out), B, cin, Tin, cout, Tout, ks, stride, pad, dil, int(tr), K,
+               int(act), float(slope), ops._dt(x_cl), ops._stream())
+        return y
+
+
+class GeneratorFused:
+    """The whole generator in channels-last layout: 1 transpose + 1 attention launch for the mel input, then
+    input_proj(+FiLM) -> 4x ODConvT(+LeakyReLU, +pooling for the next layer) -> 3x fused MRF -> out conv + tanh."""
+
+    def __init__(self, gen):
+        self.gen = gen
+        self.inp = OdconvFused(gen.input_proj)
+        self.ups = [OdconvFused(l[0]) for l in gen.upsample_layers]
+        self.mrfs = [mrf_fused_for(b) for b in gen.mrf_blocks]
+        self._wt = {}
+
+    def supported(self) -> bool:
+        g = self.gen
+        ok = self.inp.supported() and all(u.supported() for u in self.ups) and all(m is not None for m in self.mrfs)
+        k = g.output_proj.kernel_size[0]
+        return bool(ok and g.output_proj.in_channels == 64 and k % 2 == 1 and g.output_proj.padding[0] == k // 2)
+
+    def out_weights(self, device):
+        w, b = self.gen.output_proj.weight, self.gen.output_proj.bias
+        ver = (w._version, w.data_ptr(), b._version)
+        hit = self._wt.get("w")
+        if hit is not None and hit[0] == ver and hit[1].device == device:
+            return hit[1], hit[2]
+        C, ks = w.shape[1], w.shape[2]
+        wt = torch.empty(ks, C, device=device, dtype=torch.float32)
+        wd = w.detach().contiguous()
+        N.call("mv_conv_out_pack", c_void_p(wd.data_ptr()), ops._DT[wd.dtype], c_void_p(wt.data_ptr()), C, ks, ops._stream())
+        bias = float(b.detach().float().item())   # host read of one scalar, once per weight version
+        self._wt["w"] = (ver, wt, bias)
+        return wt, bias
+
+    def forward(self, mel, speaker_emb=None, emotion_emb=None, cache=None, return_stages=False):
+        g = self.gen
+        dt = mel.dtype
+        st = {}
+        B = mel.shape[0]
+        mel = mel if mel.is_contiguous() else mel.contiguous()
+        att = g.input_proj.kernel_attention[1]
+        K0, C0 = att.weight.shape[0], att.weight.shape[1]
+        alpha0 = ops.odconv_attn(mel, cache.get(att.weight, dt).view(K0, C0), cache.get(att.bias, dt))
+        x = ops.nct_to_ntc(mel)
+        film_proj, F = None, 0
+        cond = g.final_film.condition(speaker_emb, emotion_emb)
+        if cond is not None:
+            fp = g.final_film.condition_projection
+            film_proj = ops.linear(ops.cast(cond, dt), cache.get(fp.weight, dt), cache.get(fp.bias, dt))
+            F = g.final_film.feature_dim
+        chans = [u.mod.in_channels for u in self.ups]
+        # pooled channel sums handed from each producer to its consumer: dense [B][Cin] views of ONE zero fill
+        flat = torch.zeros(sum(B * c for c in chans), device=mel.device, dtype=torch.float32)
+        views, o = [], 0
+        for c in chans:
+            views.append(flat[o:o + B * c].view(B, c))
+            o += B * c
+        x = self.inp.forward_cl(x, cache, alpha=alpha0, film_proj=film_proj, film_F=F, pooled_out=views[0])
+        if return_stages:
+            st["film" if cond is not None else "input_proj"] = x
+        for i, u in enumerate(self.ups):
+            nxt = views[i + 1] if i + 1 < len(self.ups) else None
+            x = u.forward_cl(x, cache, pooled_in=views[i], pooled_out=nxt, act=N.ACT_LRELU,
+                             slope=g.upsample_layers[i][1].negative_slope)
+            if return_stages:
+                st[f"up{i}"] = x
+        for i, m in enumerate(self.mrfs):
+            x = m.forward_cl(x)
+            if return_stages:
+                st[f"mrf{i}"] = x
+        wt, bias = self.out_weights(mel.device)
+        Bx, T, C = x.shape
+        k = g.output_proj.kernel_size[0]
+        wave = torch.empty(Bx, 1, T, device=mel.device, dtype=dt)
+        N.call("mv_conv_out_act_cl", c_void_p(x.data_ptr()), c_void_p(wt.data_ptr()), bias, c_void_p(wave.data_ptr()),
+               Bx, T, C, k, k // 2, N.ACT_TANH, ops._dt(x), ops._stream())
+        if return_stages:
+            st = {kk: ops.ntc_to_nct(v) for kk, v in st.items()}   # stages are reported in the public NCT layout
+            st["wave"] = wave
+            return st
+        return wave
+
+
+def generator_fused_for(gen):
+    f = getattr(gen, "_mv_fused", None)
+    if f is None:
+        f = GeneratorFused(gen)
+        f = f if f.supported() else False
+        object.__setattr__(gen, "_mv_fused", f)
     return f or None

@@ -101,7 +101,14 @@ class ModifiedHiFiGANGenerator(nn.Module):
         for m in [self.input_proj] + [l[0] for l in self.upsample_layers]:
             yield from m.unused_parameters()
 
-    def forward(self, mel, speaker_emb=None, emotion_emb=None, return_stages=False):
+    def forward(self, mel, speaker_emb=None, emotion_emb=None, return_stages=False, force_generic=False):
+        if not force_generic and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+                                      ) and not (self.training and self.dropout > 0):
+            from .fused import generator_fused_for
+            fz = generator_fused_for(self)
+            if fz is not None:
+                # inference fast path: channels-last MFMA pipeline (csrc/odconv_fused.hip, mrf_fused.hip, conv_out.hip)
+                return fz.forward(mel, speaker_emb, emotion_emb, cache=Fn._cache, return_stages=return_stages)
         st = {}
         x = self.input_proj(mel)
         st["input_proj"] = x

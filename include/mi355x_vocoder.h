@@ -151,6 +151,33 @@ int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int*
                         const uint8_t* dropout_mask, float mask_scale, int B, int T, float eps, int dtype,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused ODConv1d / ODConvTranspose1d, channels-last.   replaces odconv.py:73-108 / :172-205 (attention ->
+ * sum_k alpha_k W_k -> conv in ONE launch) plus the epilogues that follow it in the generator: FiLM
+ * (grc_lora.py:111-129) after input_proj, LeakyReLU(0.1) after every upsampler.
+ *   x [B][Tin][Cin], y [B][Tout][Cout] ("NTC").  `packed` = mv_odconv_cl_pack(kernels) (MFMA A-fragment order,
+ *   mv_odconv_cl_packed_bytes bytes; kernels are [K,Cout,Cin,ks] (conv) or [K,Cin,Cout,ks] (transposed) in
+ *   param_dtype).  bias [K][Cout] in `dtype` or NULL.
+ *   alpha: fp32 [B][K] if already known; otherwise pooled_in (fp32 [B][Cin] = SUM over t of the layer input, as
+ *   accumulated by the producing launch) with att_w [K][Cin], att_b [K] in `dtype`: alpha is then formed in the prologue.
+ *   film_proj (optional): [B][2*film_F] in `dtype`; channels >= film_F pass through.
+ *   pooled_out (optional): fp32 [B][Cout], must be zero on entry; receives SUM over t of the stored outputs.
+ *   Supported: Cin % 8 == 0, Cout % 8 == 0, GEMM rows (Cout, or stride*Cout) % 16 == 0; conv: stride 1; transposed:
+ *   dilation 1 and ks % stride == 0.  Anything else returns MV_ERR_UNSUPPORTED (use the generic entry points). */
+size_t mv_odconv_cl_packed_bytes(int Cin, int Cout, int ks, int stride, int transposed, int K, int dtype);
+int mv_odconv_cl_pack(const void* kernels, int param_dtype, void* packed, int Cin, int Cout, int ks, int stride,
+                      int transposed, int K, int dtype, void* stream);
+int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
+                     const void* att_w, const void* att_b, const void* film_proj, int film_F, void* y,
+                     float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad,
+                     int dil, int transposed, int K, int act, float slope, int dtype, void* stream);
+
+/* Output projection, channels-last in, waveform out.   replaces SURVEY.md §A item 4: nn.Conv1d(C,1,ks,padding=ks/2) + torch.tanh
+ *   x [B][T][C] -> y [B][1][T].  wt = mv_conv_out_pack(weight [1,C,ks]) (fp32 [ks][C]).  C must be 64, ks odd. */
+int mv_conv_out_pack(const void* w, int param_dtype, float* wt, int C, int ks, void* stream);
+int mv_conv_out_act_cl(const void* x, const float* wt, float bias, void* y, int B, int T, int C, int ks, int pad,
+                       int act, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
