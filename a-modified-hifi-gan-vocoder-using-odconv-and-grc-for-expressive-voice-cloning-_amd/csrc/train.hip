@@ -1,0 +1,347 @@
+// Training-side kernels: GRC weight-fold backward, fused GAN / L1 / hinge losses (value + gradient in one pass),
+// log-mel spectrogram loss (forward + backward), flat-arena AdamW and the multi-tensor gradient gather.
+//   losses:   hifigan_modified/complete_vocoder.py:89-184 (LSGAN + L1), conditioned_hifigan.py:254-267 (hinge)
+//   AdamW:    conditioned_hifigan.py:219 (torch.optim.AdamW semantics: decoupled weight decay, bias correction)
+//   mel loss: defined by this build (the reference only has placeholders)
+#include "common.h"
+
+namespace mv {
+
+// ------------------------------------------------------------------------------------------- GRC fold backward
+// forward (norm_elem.hip grc_fold_kernel): comb[o'][c][j] = [c in grp(o')] Wc[o'][c_loc][j] + [j==mid] s (A B)[c][o']
+//   w_eff[o][c][j] = sum_o' Wp[o][o'] comb[o'][c][j];  b_eff[o] = sum_o' Wp[o][o'] bc[o'] + bp[o]
+template <typename P>
+__global__ __launch_bounds__(256) void grc_fold_bwd_kernel(const float* __restrict__ g_weff, const float* __restrict__ g_beff,
+                                                           const P* __restrict__ conv_w, const P* __restrict__ conv_b,
+                                                           const P* __restrict__ A, const P* __restrict__ Bm,
+                                                           const P* __restrict__ scal, const P* __restrict__ proj_w,
+                                                           float* __restrict__ g_conv_w, float* __restrict__ g_conv_b,
+                                                           float* __restrict__ g_A, float* __restrict__ g_B,
+                                                           float* __restrict__ g_s, float* __restrict__ g_proj_w,
+                                                           float* __restrict__ g_proj_b, int Cin, int Cout, int ks,
+                                                           int groups, int rank) {
+  extern __shared__ float sm[];
+  float* gcomb = sm;                         // [Cout][Cin][ks]
+  float* L = gcomb + Cout * Cin * ks;        // [Cin][Cout]
+  float* red = L + Cin * Cout;               // [32]
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int cin_g = Cin / groups, cout_g = Cout / groups, mid = ks / 2;
+  const float s = ld<P>(scal);
+  for (int i = tid; i < Cin * Cout; i += nt) {
+    const int c = i / Cout, o = i % Cout;
+    float l = 0.f;
+    for (int r = 0; r < rank; ++r) l += ld<P>(A + c * rank + r) * ld<P>(Bm + r * Cout + o);
+    L[i] = l;
+  }
+  for (int i = tid; i < Cout * Cin * ks; i += nt) {
+    const int j = i % ks, c = (i / ks) % Cin, op = i / (ks * Cin);
+    float a = 0.f;
+    for (int o = 0; o < Cout; ++o) a += ld<P>(proj_w + o * Cout + op) * g_weff[((long)o * Cin + c) * ks + j];
+    gcomb[i] = a;
+  }
+  __syncthreads();
+  // proj_w / proj_b / conv_b
+  for (int i = tid; i < Cout * Cout; i += nt) {
+    const int o = i / Cout, op = i % Cout;
+    const int g = op / cout_g;
+    float a = g_beff[o] * ld<P>(conv_b + op);
+    for (int c = 0; c < Cin; ++c)
+      for (int j = 0; j < ks; ++j) {
+        float comb = 0.f;
+        if (c / cin_g == g) comb = ld<P>(conv_w + ((long)op * cin_g + (c - g * cin_g)) * ks + j);
+        if (j == mid) comb += s * L[c * Cout + op];
+        a += g_weff[((long)o * Cin + c) * ks + j] * comb;
+      }
+    g_proj_w[i] = a;
+  }
+  for (int o = tid; o < Cout; o += nt) {
+    g_proj_b[o] = g_beff[o];
+    float a = 0.f;
+    for (int oo = 0; oo < Cout; ++oo) a += ld<P>(proj_w + oo * Cout + o) * g_beff[oo];
+    g_conv_b[o] = a;
+  }
+  for (int i = tid; i < Cout * cin_g * ks; i += nt) {
+    const int j = i % ks, cl = (i / ks) % cin_g, op = i / (ks * cin_g);
+    const int c = (op / cout_g) * cin_g + cl;
+    g_conv_w[i] = gcomb[((long)op * Cin + c) * ks + j];
+  }
+  for (int i = tid; i < Cin * rank; i += nt) {
+    const int c = i / rank, r = i % rank;
+    float a = 0.f;
+    for (int op = 0; op < Cout; ++op) a += s * gcomb[((long)op * Cin + c) * ks + mid] * ld<P>(Bm + r * Cout + op);
+    g_A[i] = a;
+  }
+  for (int i = tid; i < rank * Cout; i += nt) {
+    const int r = i / Cout, op = i % Cout;
+    float a = 0.f;
+    for (int c = 0; c < Cin; ++c) a += ld<P>(A + c * rank + r) * s * gcomb[((long)op * Cin + c) * ks + mid];
+    g_B[i] = a;
+  }
+  float part = 0.f;
+  for (int i = tid; i < Cin * Cout; i += nt) {
+    const int c = i / Cout, op = i % Cout;
+    part += L[i] * gcomb[((long)op * Cin + c) * ks + mid];
+  }
+  part = block_sum(part, red);
+  if (tid == 0) g_s[0] = part;
+}
+
+// ------------------------------------------------------------------------------------------- losses (value + gradient)
+// kind 0: mean((x-c)^2)            (LSGAN, complete_vocoder.py:104,157-158)
+// kind 1: mean(|x-y|)              (L1 / "feature matching", :118,127)          gy (optional) = -gx
+// kind 2: mean(relu(1 - x))        (hinge generator, conditioned_hifigan.py:263)
+// kind 3: mean(relu(1 + x))        (hinge discriminator-fake, :265)
+// kind 4: mean((x-y)^2)            (MSE between tensors, conditioned_hifigan.py:238)
+// loss_acc[0] += weight * value ; gx = weight * d value / dx
+template <typename T>
+__global__ __launch_bounds__(256) void loss_kernel(const T* __restrict__ x, const T* __restrict__ y, float c, float weight,
+                                                   float* __restrict__ loss_acc, T* __restrict__ gx, T* __restrict__ gy,
+                                                   long n, int kind) {
+  __shared__ float red[32];
+  const float inv = weight / (float)n;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = ld<T>(x + i);
+    float l, g;
+    if (kind == 0) { const float d = v - c; l = d * d; g = 2.f * d; }
+    else if (kind == 1) { const float d = v - ld<T>(y + i); l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    else if (kind == 2) { const float d = 1.f - v; l = d > 0.f ? d : 0.f; g = d > 0.f ? -1.f : 0.f; }
+    else if (kind == 3) { const float d = 1.f + v; l = d > 0.f ? d : 0.f; g = d > 0.f ? 1.f : 0.f; }
+    else { const float d = v - ld<T>(y + i); l = d * d; g = 2.f * d; }
+    s += l;
+    if (gx) st<T>(gx + i, g * inv);
+    if (gy) st<T>(gy + i, -g * inv);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(loss_acc, s * inv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, const float* __restrict__ factor_dev, float factor, long n) {
+  const float f = factor_dev ? factor * factor_dev[0] : factor;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    st<T>(x + i, ld<T>(x + i) * f);
+}
+
+// ------------------------------------------------------------------------------------------- AdamW on a flat fp32 arena
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);                 // decoupled weight decay (torch.optim.AdamW)
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+
+// gather many gradient tensors (any storage type, given per tensor) into one flat fp32 buffer
+struct GatherDesc { const void* src; long dst_off; long n; int dtype; int pad; };
+__global__ __launch_bounds__(256) void multi_gather_kernel(const GatherDesc* __restrict__ descs, float* __restrict__ flat, int chunk) {
+  const GatherDesc d = descs[blockIdx.y];
+  const long beg = (long)blockIdx.x * chunk;
+  if (beg >= d.n) return;
+  const long end = beg + chunk < d.n ? beg + chunk : d.n;
+  for (long i = beg + threadIdx.x; i < end; i += blockDim.x) {
+    float v;
+    if (d.src == nullptr) v = 0.f;
+    else if (d.dtype == MV_F32) v = ((const float*)d.src)[i];
+    else if (d.dtype == MV_BF16) v = ld<bf16>((const bf16*)d.src + i);
+    else v = ld<f16>((const f16*)d.src + i);
+    flat[d.dst_off + i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- log-mel spectrogram loss
+// frames: reflect-pad (n_fft-hop)/2, hop, periodic Hann; |rDFT| (direct O(N^2) DFT with an exact (k*n mod N) twiddle table
+// in LDS), mel = fb @ mag, logmel = log(max(mel, clamp)); loss = weight * mean |logmel - target|.
+// One workgroup per (b, frame).  Backward recomputes the frame spectrum and scatters d wave with atomics (frames overlap 4x).
+__device__ __forceinline__ int reflect_idx(int i, int Tn) {
+  if (i < 0) i = -i;
+  if (i >= Tn) i = 2 * (Tn - 1) - i;
+  return i;
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wave, const float* __restrict__ fb,
+                                                       const T* __restrict__ target, float* __restrict__ mel_out,
+                                                       float* __restrict__ loss_acc, float* __restrict__ gwave,
+                                                       int Tn, int n_fft, int hop, int n_mels, int n_frames, float clampv,
+                                                       float weight, long n_total, int kind) {
+  extern __shared__ float sm[];
+  const int nb = n_fft / 2 + 1;
+  float* fr = sm;                 // [n_fft] windowed frame
+  float* ct = fr + n_fft;         // [n_fft] cos table
+  float* stb = ct + n_fft;        // [n_fft] sin table
+  float* re = stb + n_fft;        // [nb]
+  float* im = re + nb;            // [nb]
+  float* mag = im + nb;           // [nb]  (bwd: reused for g_mag)
+  float* gml = mag + nb;          // [n_mels] dL/dmel
+  float* red = gml + n_mels;      // [32]
+  const int b = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
+  const int padn = (n_fft - hop) / 2;
+  const float w0 = 6.283185307179586f / (float)n_fft;
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    const float win = 0.5f - 0.5f * cosf(w0 * n);
+    const int ti = reflect_idx(f * hop - padn + n, Tn);
+    fr[n] = ld<T>(wave + (long)b * Tn + ti) * win;
+    ct[n] = cosf(w0 * n);
+    stb[n] = sinf(w0 * n);
+  }
+  __syncthreads();
+  for (int k = tid; k < nb; k += blockDim.x) {
+    float a = 0.f, c = 0.f;
+    int idx = 0;
+    for (int n = 0; n < n_fft; ++n) {
+      a += fr[n] * ct[idx];
+      c -= fr[n] * stb[idx];
+      idx += k; if (idx >= n_fft) idx -= n_fft;
+    }
+    re[k] = a; im[k] = c;
+    mag[k] = sqrtf(a * a + c * c + 1e-9f);
+  }
+  __syncthreads();
+  float lsum = 0.f;
+  for (int m = tid; m < n_mels; m += blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < nb; ++k) a += fb[(long)m * nb + k] * mag[k];
+    const float lm = logf(fmaxf(a, clampv));
+    if (mel_out) mel_out[((long)b * n_mels + m) * n_frames + f] = lm;
+    float g = 0.f;
+    if (target) {
+      const float d = lm - ld<T>(target + ((long)b * n_mels + m) * n_frames + f);
+      lsum += kind == 0 ? fabsf(d) : d * d;
+      g = (kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * (weight / (float)n_total);
+    }
+    gml[m] = (a > clampv) ? g / a : 0.f;       // d/d mel through log(clamp)
+  }
+  if (loss_acc && target) {
+    lsum = block_sum(lsum, red);
+    if (tid == 0) atomicAdd(loss_acc, lsum * weight / (float)n_total);
+  }
+  if (!BWD) return;
+  __syncthreads();
+  // g_mag[k] = sum_m fb[m][k] gml[m] ; g_re = g_mag re/mag ; g_im = g_mag im/mag
+  for (int k = tid; k < nb; k += blockDim.x) {
+    float a = 0.f;
+    for (int m = 0; m < n_mels; ++m) a += fb[(long)m * nb + k] * gml[m];
+    const float inv = a / mag[k];
+    re[k] *= inv; im[k] *= inv;    // now g_re, g_im
+  }
+  __syncthreads();
+  // g_frame[n] = sum_k g_re cos(2 pi k n/N) - g_im sin(2 pi k n/N) ; d wave += g_frame * win
+  for (int n = tid; n < n_fft; n += blockDim.x) {
+    float a = 0.f;
+    int idx = 0;
+    for (int k = 0; k < nb; ++k) {
+      a += re[k] * ct[idx] - im[k] * stb[idx];
+      idx += n; if (idx >= n_fft) idx -= n_fft;
+    }
+    const float win = 0.5f - 0.5f * ct[n];
+    const int ti = reflect_idx(f * hop - padn + n, Tn);
+    atomicAdd(gwave + (long)b * Tn + ti, a * win);
+  }
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+static inline int grid_for(long n, int block = 256, int cap = 2048) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int mv_grc_fold_bwd(const float* g_weff, const float* g_beff, const void* conv_w, const void* conv_b,
+                               const void* lora_A, const void* lora_B, const void* lora_scaling, const void* proj_w,
+                               float* g_conv_w, float* g_conv_b, float* g_A, float* g_B, float* g_s, float* g_proj_w,
+                               float* g_proj_b, int Cin, int Cout, int ks, int groups, int rank, int param_dtype,
+                               void* stream) {
+  MV_CHECK_ARG(g_weff && g_beff && conv_w && conv_b && lora_A && lora_B && lora_scaling && proj_w);
+  MV_CHECK_ARG(g_conv_w && g_conv_b && g_A && g_B && g_s && g_proj_w && g_proj_b && (ks & 1) && Cin % groups == 0 && Cout % groups == 0);
+  const size_t lds = sizeof(float) * ((size_t)Cout * Cin * ks + (size_t)Cin * Cout + 32);
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+#define GO(P) { auto kern = grc_fold_bwd_kernel<P>; \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, (hipStream_t)stream, g_weff, g_beff, (const P*)conv_w, (const P*)conv_b, \
+      (const P*)lora_A, (const P*)lora_B, (const P*)lora_scaling, (const P*)proj_w, g_conv_w, g_conv_b, g_A, g_B, g_s, g_proj_w, \
+      g_proj_b, Cin, Cout, ks, groups, rank); }
+  switch (param_dtype) {
+    case MV_F32: GO(float); break;
+    case MV_BF16: GO(bf16); break;
+    case MV_F16: GO(f16); break;
+    default: return MV_ERR_DTYPE;
+  }
+#undef GO
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_loss_fwd_bwd(const void* x, const void* y, float c, float weight, float* loss_acc, void* gx, void* gy,
+                               long n, int kind, int dtype, void* stream) {
+  MV_CHECK_ARG(x && loss_acc && n > 0 && kind >= 0 && kind <= 4 && ((kind != 1 && kind != 4) || y));
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(loss_kernel<T>, dim3(grid_for(n, 256, 512)), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)x, (const T*)y, c, weight, loss_acc, (T*)gx, (T*)gy, n, kind));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_scale(void* x, const float* factor_dev, float factor, long n, int dtype, void* stream) {
+  MV_CHECK_ARG(x && n > 0);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(scale_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (T*)x,
+                                        factor_dev, factor, n));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  MV_CHECK_ARG(p && g && m && v && n > 0 && step >= 1);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_multi_gather(const void* descs_dev, int n_tensors, long max_len, float* flat, void* stream) {
+  MV_CHECK_ARG(descs_dev && flat && n_tensors > 0 && n_tensors <= 65535 && max_len > 0);
+  const int chunk = 16384;
+  dim3 grid((unsigned)((max_len + chunk - 1) / chunk), n_tensors);
+  hipLaunchKernelGGL(multi_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const GatherDesc*)descs_dev, flat, chunk);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mel_loss(const void* wave, const float* fb, const void* target, float* mel_out, float* loss_acc,
+                           float* gwave, int B, int T_, int n_fft, int hop, int n_mels, float clampv, float weight,
+                           int kind, int backward, int dtype, void* stream) {
+  MV_CHECK_ARG(wave && fb && B > 0 && T_ > 0 && n_fft > 0 && hop > 0 && n_mels > 0 && T_ % hop == 0 && n_fft >= hop);
+  MV_CHECK_ARG(!backward || (gwave && target));
+  MV_CHECK_ARG(kind == 0 || kind == 1);
+  MV_CHECK_ARG((n_fft - hop) / 2 < T_);
+  const int n_frames = T_ / hop, nb = n_fft / 2 + 1;
+  const size_t lds = sizeof(float) * (3 * (size_t)n_fft + 3 * (size_t)nb + n_mels + 32);
+  if (lds > 160 * 1024 || B > 65535) return MV_ERR_UNSUPPORTED;
+  const long n_total = (long)B * n_mels * n_frames;
+  dim3 grid(n_frames, B);
+  MV_DISPATCH(dtype, {
+    if (backward) {
+      auto kern = mel_loss_kernel<T, true>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, (const T*)target, mel_out,
+                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
+    } else {
+      auto kern = mel_loss_kernel<T, false>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, (const T*)target, mel_out,
+                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
+    }
+  });
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -7,6 +7,8 @@ from .odconv import ODConv1d, ODConvTranspose1d
 from .grc_lora import GRC_LoRA_Block, FiLMLayer, MultiReceptiveFieldBlock
 from .generator import (ModifiedHiFiGANGenerator, HiFiGANGenerator, GroupedResidualConv1D,
                         FeatureWiseLinearModulation)
+from .complete_vocoder import ModifiedHiFiGANVocoder, VocoderTrainer
+from .conditioned_hifigan import ConditionedHiFiGAN, HiFiGANTrainer
 from .discriminators import (HiFiGANDiscriminators, MultiPeriodDiscriminator, MultiScaleDiscriminator,
                              Discriminator1D, Discriminator2D)
 
@@ -14,5 +16,5 @@ __all__ = [
     "ODConv1d", "ODConvTranspose1d", "GRC_LoRA_Block", "FiLMLayer", "MultiReceptiveFieldBlock",
     "ModifiedHiFiGANGenerator", "HiFiGANGenerator", "GroupedResidualConv1D", "FeatureWiseLinearModulation",
     "HiFiGANDiscriminators", "MultiPeriodDiscriminator", "MultiScaleDiscriminator", "Discriminator1D",
-    "Discriminator2D",
+    "Discriminator2D", "ModifiedHiFiGANVocoder", "VocoderTrainer", "ConditionedHiFiGAN", "HiFiGANTrainer",
 ]

@@ -87,8 +87,18 @@ def check(rc, name):
     raise RuntimeError(f"{name}: HIP launch failed with hipError_t={rc}")
 
 
+_TRACE = bool(os.environ.get("MV_TRACE"))   # debugging aid: print every entry point and synchronise after it
+
+
 def call(name, *args):
     fn = getattr(lib(), name)
+    if _TRACE:
+        import sys
+        import torch
+        print(f"[mv] {name}", file=sys.stderr, flush=True)
+        check(fn(*args), name)
+        torch.cuda.synchronize()
+        return
     check(fn(*args), name)
 
 

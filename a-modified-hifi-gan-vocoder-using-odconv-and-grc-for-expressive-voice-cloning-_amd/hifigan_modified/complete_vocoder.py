@@ -1,0 +1,168 @@
+"""Complete vocoder system + two-optimizer trainer on MI355X.
+
+Drop-in for the reference's ``hifigan_modified/complete_vocoder.py``: ``ModifiedHiFiGANVocoder`` (:21-184: generator +
+discriminators, LSGAN + output-L1 "feature matching" + mel-L1 losses, weights 10 / 45) and ``VocoderTrainer``
+(:186-248: G forward once -> D step on the detached fake -> G step with the discriminators re-evaluated).
+
+Differences, all documented in DESIGN.md: the generator is the one ``conditioned_hifigan`` is written against (SURVEY.md
+§A; the reference's current-source generator does not construct); the embedding extractor (``embedding_extractors.py``,
+out of scope and broken upstream) is not built - pass embeddings explicitly; the mel term is a real log-mel/STFT L1
+(``mel_mode="stft"``) instead of the reference's ``generated_mel = mel`` placeholder (``mel_mode="placeholder"``
+reproduces that: the term is then identically zero).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import functional as Fn
+from .discriminators import HiFiGANDiscriminators
+from .generator import ModifiedHiFiGANGenerator
+from .mel import mel_filterbank
+
+
+class ModifiedHiFiGANVocoder(nn.Module):
+    def __init__(self, input_channels: int = 80, hidden_channels: int = 512,
+                 speaker_embedding_dim: int = 192, emotion_embedding_dim: int = 256,
+                 sample_rate: int = 22050, n_fft: int = 1024, hop: Optional[int] = None, **generator_kwargs):
+        super().__init__()
+        self.generator = ModifiedHiFiGANGenerator(mel_channels=input_channels, hidden_channels=hidden_channels,
+                                                  speaker_embedding_dim=speaker_embedding_dim,
+                                                  emotion_embedding_dim=emotion_embedding_dim, **generator_kwargs)
+        self.discriminators = HiFiGANDiscriminators()
+        self.embedding_extractor = None     # conditioning producer: out of scope
+        self.fm_weight = 10.0
+        self.mel_weight = 45.0
+        hop_total = 1
+        for f in self.generator.upsample_factors:
+            hop_total *= f
+        self.n_fft, self.hop = n_fft, hop or hop_total
+        self.register_buffer("mel_fb", mel_filterbank(sample_rate, n_fft, input_channels), persistent=False)
+
+    def forward(self, mel_spectrogram, speaker_embedding=None, emotion_embedding=None,
+                extract_embeddings: bool = True) -> Dict[str, torch.Tensor]:
+        wave = self.generator(mel_spectrogram, speaker_embedding, emotion_embedding)
+        return {"generated_waveform": wave, "speaker_embedding": speaker_embedding, "emotion_embedding": emotion_embedding}
+
+    def get_discriminator_outputs(self, real_audio, fake_audio):
+        return self.discriminators(real_audio, fake_audio)
+
+    def log_mel(self, audio):
+        """log-mel [B, n_mels, T/hop] of a waveform (HIP STFT kernel)."""
+        return Fn.mel_spectrogram(audio, self.mel_fb, self.n_fft, self.hop)
+
+    # ---- losses (complete_vocoder.py:89-184)
+    def compute_generator_losses(self, real_audio, fake_audio, mel_spectrogram, generated_mel=None):
+        """generated_mel tensor -> L1(generated_mel, mel_spectrogram) like the reference; None -> the mel of
+        `fake_audio` is taken by the STFT kernel and compared with `mel_spectrogram` (a log-mel target)."""
+        D = self.discriminators
+        with torch.no_grad():               # D(real) only enters through .detach() (complete_vocoder.py:118,123)
+            mpd_real, msd_real = D.mpd(real_audio), D.msd(real_audio)
+        mpd_fake, msd_fake = D.mpd(fake_audio), D.msd(fake_audio)
+        mpd_loss = sum(Fn.mse_const(f, 1.0) for f in mpd_fake)
+        msd_loss = sum(Fn.mse_const(f, 1.0) for f in msd_fake)
+        mpd_fm = sum(Fn.l1(f, r) for r, f in zip(mpd_real, mpd_fake))
+        msd_fm = sum(Fn.l1(f, r) for r, f in zip(msd_real, msd_fake))
+        if generated_mel is None:
+            mel_loss = Fn.mel_l1(fake_audio, mel_spectrogram, self.mel_fb, self.n_fft, self.hop)
+        else:
+            mel_loss = Fn.l1(generated_mel, mel_spectrogram)
+        total = mpd_loss + msd_loss + self.fm_weight * (mpd_fm + msd_fm) + self.mel_weight * mel_loss
+        return {"total_loss": total, "mpd_loss": mpd_loss, "msd_loss": msd_loss, "mpd_fm_loss": mpd_fm,
+                "msd_fm_loss": msd_fm, "mel_loss": mel_loss}
+
+    def compute_discriminator_losses(self, real_audio, fake_audio):
+        out = self.discriminators(real_audio, fake_audio)
+        mpd_real = sum(Fn.mse_const(o, 1.0) for o in out["mpd_real"])
+        mpd_fake = sum(Fn.mse_const(o, 0.0) for o in out["mpd_fake"])
+        msd_real = sum(Fn.mse_const(o, 1.0) for o in out["msd_real"])
+        msd_fake = sum(Fn.mse_const(o, 0.0) for o in out["msd_fake"])
+        return {"total_loss": mpd_real + mpd_fake + msd_real + msd_fake, "mpd_real_loss": mpd_real,
+                "mpd_fake_loss": mpd_fake, "msd_real_loss": msd_real, "msd_fake_loss": msd_fake}
+
+
+class VocoderTrainer:
+    """complete_vocoder.py:186-248.  Optimizers: anything with zero_grad()/step(); `FlatAdamW` (optim.py) is the native
+    one and is what `default_optimizers` builds (lr 2e-4, betas (0.8, 0.99), wd 1e-4: configs/train_config.yaml:54-72).
+    `grad_sync` (parallel.GradSynchronizer) adds the data-parallel all-reduce."""
+
+    def __init__(self, vocoder: ModifiedHiFiGANVocoder, generator_optimizer=None, discriminator_optimizer=None,
+                 device=None, mel_mode: str = "stft", grad_sync=None):
+        device = device or torch.device("cuda")
+        self.vocoder = vocoder.to(device)
+        self.device = device
+        if generator_optimizer is None or discriminator_optimizer is None:
+            generator_optimizer, discriminator_optimizer = self.default_optimizers(self.vocoder)
+        self.generator_optimizer = generator_optimizer
+        self.discriminator_optimizer = discriminator_optimizer
+        self.mel_mode = mel_mode
+        self.grad_sync = grad_sync
+        self._d_params = list(self.vocoder.discriminators.parameters())
+
+    @staticmethod
+    def default_optimizers(vocoder, lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-4):
+        from .optim import FlatAdamW
+        g = FlatAdamW(vocoder.generator.parameters(), lr=lr, betas=betas, weight_decay=weight_decay,
+                      exclude=list(vocoder.generator.unused_parameters()))
+        d = FlatAdamW(vocoder.discriminators.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)
+        return g, d
+
+    def _step(self, opt):
+        from .optim import FlatAdamW
+        if isinstance(opt, FlatAdamW):
+            flat = opt.gather_grads()
+            scale = 1.0
+            if self.grad_sync is not None:
+                self.grad_sync.start(flat)
+                scale = self.grad_sync.finish()
+            opt.step(grad_scale=scale, gathered=True)
+        else:
+            opt.step()
+
+    def train_step(self, mel_spectrogram, real_audio, speaker_embedding=None, emotion_embedding=None) -> Dict[str, float]:
+        mel_spectrogram = mel_spectrogram.to(self.device)
+        real_audio = real_audio.to(self.device)
+        out = self.vocoder(mel_spectrogram, speaker_embedding, emotion_embedding)
+        fake_audio = out["generated_waveform"]
+        # discriminator step on the detached fake
+        self.discriminator_optimizer.zero_grad()
+        d_losses = self.vocoder.compute_discriminator_losses(real_audio, fake_audio.detach())
+        d_losses["total_loss"].backward()
+        self._step(self.discriminator_optimizer)
+        # generator step: discriminators re-evaluated after their update; their own weight gradients are not needed
+        # (the reference accumulates and then zeroes them at the next D step)
+        self.generator_optimizer.zero_grad()
+        for p in self._d_params:
+            p.requires_grad_(False)
+        try:
+            if self.mel_mode == "stft":
+                target = self.vocoder.log_mel(real_audio)
+                g_losses = self.vocoder.compute_generator_losses(real_audio, fake_audio, target, None)
+            else:   # the reference's placeholder: generated_mel = mel_spectrogram -> the term is zero
+                g_losses = self.vocoder.compute_generator_losses(real_audio, fake_audio, mel_spectrogram, mel_spectrogram)
+            g_losses["total_loss"].backward()
+        finally:
+            for p in self._d_params:
+                p.requires_grad_(True)
+        self._step(self.generator_optimizer)
+        self.last_losses = (g_losses, d_losses)
+        return {"generator_loss": g_losses["total_loss"], "discriminator_loss": d_losses["total_loss"],
+                "mel_loss": g_losses["mel_loss"]}
+
+    @staticmethod
+    def to_floats(losses):
+        """Host read-back of a loss dict (kept out of train_step so a step does not force a device sync)."""
+        return {k: float(v) for k, v in losses.items()}
+
+    def save_checkpoint(self, path: str):
+        torch.save({"vocoder_state_dict": self.vocoder.state_dict(),
+                    "generator_optimizer_state_dict": self.generator_optimizer.state_dict(),
+                    "discriminator_optimizer_state_dict": self.discriminator_optimizer.state_dict()}, path)
+
+    def load_checkpoint(self, path: str):
+        ck = torch.load(path, map_location=self.device, weights_only=True)
+        self.vocoder.load_state_dict(ck["vocoder_state_dict"])
+        self.generator_optimizer.load_state_dict(ck["generator_optimizer_state_dict"])
+        self.discriminator_optimizer.load_state_dict(ck["discriminator_optimizer_state_dict"])

@@ -1,12 +1,15 @@
 """Differentiable building blocks of the vocoder path, expressed over the HIP ops in ``ops.py``.
 
-Each public function corresponds to one reference module's forward (cited below).  Parameters are
-taken as they live in the nn.Module (fp32 masters or already low precision) and are cast to the
-activation dtype through a version-keyed cache.
+Each public function corresponds to one reference module's forward (cited below) and is a
+``torch.autograd.Function`` whose forward AND backward are HIP kernels (include/mi355x_vocoder.h);
+torch only threads the graph together.  Parameters are taken as they live in the nn.Module (fp32
+masters or already low precision) and are cast to the activation dtype through a version-keyed cache;
+parameter gradients are produced in fp32 and cast to the parameter's dtype.
 """
 from __future__ import annotations
 
 import torch
+from torch.autograd import Function
 
 from . import _native as N
 from . import ops
@@ -19,10 +22,16 @@ def _w(p, like):
     return _cache.get(p, like.dtype)
 
 
-class _Pending(torch.autograd.Function):
-    """Marks an output as differentiable-in-principle: the forward is the HIP path; asking for a
-    gradient through an op whose backward kernels are not built yet fails loudly instead of silently
-    returning zeros."""
+def _to(g, p):
+    """fp32 gradient -> the parameter's dtype/shape."""
+    if g is None:
+        return None
+    g = g.view(p.shape)
+    return g if g.dtype == p.dtype else ops.cast(g, p.dtype)
+
+
+class _Pending(Function):
+    """Forward-only ops (second-design blocks): asking for a gradient fails loudly instead of returning zeros."""
 
     @staticmethod
     def forward(ctx, name, y, *deps):
@@ -41,51 +50,197 @@ def _track(name, y, *deps):
 
 
 # ----------------------------------------------------------------------------------------------- ODConv
+class _ODConv(Function):
+    """odconv.py:73-108 / :172-205.  cfg = (transposed, stride, padding, output_padding, dilation, act, slope)."""
+
+    @staticmethod
+    def forward(ctx, x, kernels, bias, att_w, att_b, cfg):
+        transposed, stride, padding, out_pad, dilation, act, slope = cfg
+        x = x if x.is_contiguous() else x.contiguous()
+        K, C = att_w.shape[0], att_w.shape[1]
+        wa, wk, wb = _w(att_w, x).view(K, C), _w(kernels, x), _w(bias, x)
+        alpha, pooled = ops.odconv_attn(x, wa, _w(att_b, x), want_pooled=True)
+        if transposed:
+            y = ops.conv_transpose1d(x, wk, wb, alpha, stride, padding, out_pad, dilation, act, slope)
+        else:
+            y = ops.conv1d(x, wk, wb, alpha, stride, padding, dilation, 1, act, slope)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, kernels, bias, att_w, att_b, alpha, pooled, y if act != N.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, kernels, bias, att_w, att_b, alpha, pooled, y = ctx.saved_tensors
+        transposed, stride, padding, out_pad, dilation, act, slope = ctx.cfg
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        g = ops.act_bwd(gy, y, act, slope) if act != N.ACT_NONE else gy
+        K, C = att_w.shape[0], att_w.shape[1]
+        wk = _w(kernels, x)
+        ks = kernels.shape[3]
+        B, Cin, Tin = x.shape
+        Tout = g.shape[2]
+        # data gradient: the adjoint convolution with the same (alpha-aggregated) kernels
+        if transposed:
+            gx = ops.conv1d(g, wk, None, alpha, stride, padding, dilation, 1)
+        else:
+            opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)
+            gx = ops.conv_transpose1d(g, wk, None, alpha, stride, padding, opad, dilation)
+        # kernel-bank gradient + d alpha = <per-sample wgrad, W_k>
+        if transposed:   # same kernel with the roles of input and output-gradient swapped
+            gw, galpha = ops.conv1d_wgrad(g, x, wk, alpha, ks, stride, padding, dilation)
+        else:
+            gw, galpha = ops.conv1d_wgrad(x, g, wk, alpha, ks, stride, padding, dilation)
+        gb = ops.bias_grad(g, alpha, _w(bias, x), galpha)
+        gwa, gba, gm = ops.odconv_attn_bwd(alpha, galpha, pooled, _w(att_w, x).view(K, C), Tin)
+        ops.add_rowconst_(gx, gm)          # the pooling path: (1/T) Wa^T gz added to every time step
+        return gx, _to(gw, kernels), _to(gb, bias), _to(gwa, att_w), _to(gba, att_b), None
+
+
 def odconv_attention(x, att_w, att_b):
-    """odconv.py:36-40,85."""
+    """odconv.py:36-40,85 (inspection helper; not differentiable on its own)."""
     K, C = att_w.shape[0], att_w.shape[1]
     with torch.no_grad():
-        alpha = ops.odconv_attn(x, _w(att_w, x).view(K, C), _w(att_b, x))
-    return _track("odconv_attention", alpha, x, att_w, att_b)
+        return ops.odconv_attn(x, _w(att_w, x).view(K, C), _w(att_b, x))
 
 
 def odconv1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, dilation=1, act=None, slope=0.1):
-    """odconv.py:73-108: attention, then ONE launch doing aggregate + conv (+ act)."""
-    with torch.no_grad():
-        K, C = att_w.shape[0], att_w.shape[1]
-        alpha = ops.odconv_attn(x, _w(att_w, x).view(K, C), _w(att_b, x))
-        y = ops.conv1d(x, _w(kernels, x), _w(bias, x), alpha, stride, padding, dilation, 1, _ACT[act], slope)
-    return _track("odconv1d", y, x, kernels, bias, att_w, att_b)
+    return _ODConv.apply(x, kernels, bias, att_w, att_b, (False, stride, padding, 0, dilation, _ACT[act], slope))
 
 
 def odconv_transpose1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, output_padding=0, dilation=1,
                        act=None, slope=0.1):
-    """odconv.py:172-205."""
-    with torch.no_grad():
-        K, C = att_w.shape[0], att_w.shape[1]
-        alpha = ops.odconv_attn(x, _w(att_w, x).view(K, C), _w(att_b, x))
-        y = ops.conv_transpose1d(x, _w(kernels, x), _w(bias, x), alpha, stride, padding, output_padding, dilation,
-                                 _ACT[act], slope)
-    return _track("odconv_transpose1d", y, x, kernels, bias, att_w, att_b)
+    return _ODConv.apply(x, kernels, bias, att_w, att_b, (True, stride, padding, output_padding, dilation, _ACT[act], slope))
 
 
-# ----------------------------------------------------------------------------------------------- plain layers
+# ----------------------------------------------------------------------------------------------- plain convolutions
+class _Conv1d(Function):
+    """nn.Conv1d (+ fused activation).  cfg = (stride, padding, dilation, groups, act, slope)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        stride, padding, dilation, groups, act, slope = cfg
+        x = x if x.stride(2) == 1 else x.contiguous()
+        y = ops.conv1d(x, _w(weight, x), _w(bias, x), None, stride, padding, dilation, groups, act, slope)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, weight, bias, y if act != N.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, y = ctx.saved_tensors
+        stride, padding, dilation, groups, act, slope = ctx.cfg
+        if groups != 1:
+            raise NotImplementedError("mi355x vocoder: backward of grouped conv1d is not available in this build")
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        g = ops.act_bwd(gy, y, act, slope) if act != N.ACT_NONE else gy
+        ks = weight.shape[2]
+        Tin, Tout = x.shape[2], g.shape[2]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)
+            gx = ops.conv_transpose1d(g, _w(weight, x), None, None, stride, padding, opad, dilation)
+        if ctx.needs_input_grad[1]:
+            gw, _ = ops.conv1d_wgrad(x, g, None, None, ks, stride, padding, dilation)
+            gw = _to(gw, weight)
+        if bias is not None and ctx.needs_input_grad[2]:
+            gb = _to(ops.bias_grad(g), bias)
+        return gx, gw, gb, None
+
+
 def conv1d(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, act=None, slope=0.1):
-    with torch.no_grad():
-        y = ops.conv1d(x, _w(weight, x), _w(bias, x), None, stride, padding, dilation, groups, _ACT[act], slope)
-    return _track("conv1d", y, x, weight, bias)
+    return _Conv1d.apply(x, weight, bias, (stride, padding, dilation, groups, _ACT[act], slope))
+
+
+class _Conv2d(Function):
+    """nn.Conv2d stride 1 (+ LeakyReLU) - discriminators.py:57-65."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        padding, act, slope = cfg
+        y = ops.conv2d(x, _w(weight, x), _w(bias, x), padding, act, slope)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, weight, bias, y if act != N.ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias, y = ctx.saved_tensors
+        (ph, pw), act, slope = ctx.cfg
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        g = ops.act_bwd(gy, y, act, slope) if act != N.ACT_NONE else gy
+        kh, kw = weight.shape[2], weight.shape[3]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv2d(g, ops.conv2d_flip_weights(_w(weight, x)), None, (kh - 1 - ph, kw - 1 - pw))
+        if ctx.needs_input_grad[1]:
+            gw = _to(ops.conv2d_wgrad(x, g, kh, kw, ph, pw), weight)
+        if bias is not None and ctx.needs_input_grad[2]:
+            B, C, H, W = g.shape
+            gb = _to(ops.bias_grad(g.view(B, C, H * W)), bias)
+        return gx, gw, gb, None
+
+
+def conv2d(x, weight, bias, padding=(1, 1), act=None, slope=0.1):
+    return _Conv2d.apply(x, weight, bias, (tuple(padding), _ACT[act], slope))
+
+
+# ----------------------------------------------------------------------------------------------- GroupNorm (+act, +dropout, +residual)
+class _GroupNorm(Function):
+    """y = act(GN(x)) * mask*scale + res   (grc_lora.py:58-59,68 and :161-163).  cfg = (G, eps, act, slope, mask_scale)."""
+
+    @staticmethod
+    def forward(ctx, x, gw, gb, res, mask, cfg):
+        G, eps, act, slope, mask_scale = cfg
+        x = x if x.stride(2) == 1 else x.contiguous()
+        mean, rstd = ops.groupnorm_stats(x, G, eps)
+        if res is not None and res.stride(2) != 1:
+            res = res.contiguous()
+        y = ops.groupnorm_apply(x, mean, rstd, _w(gw, x), _w(gb, x), G, act, slope, res, mask, mask_scale)
+        ctx.cfg = cfg
+        ctx.has_res = res is not None
+        ctx.save_for_backward(x, gw, gb, mean, rstd, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gw, gb, mean, rstd, mask = ctx.saved_tensors
+        G, eps, act, slope, mask_scale = ctx.cfg
+        gy = gy if gy.stride(2) == 1 else gy.contiguous()
+        gx, dgw, dgb = ops.groupnorm_bwd(x, gy, mean, rstd, _w(gw, x), _w(gb, x), G, act, slope, mask, mask_scale)
+        return gx, _to(dgw, gw), _to(dgb, gb), (gy if ctx.has_res else None), None, None
+
+
+def group_norm(x, gw, gb, G, eps=1e-5, act=None, slope=0.1, res=None, mask=None, mask_scale=1.0):
+    return _GroupNorm.apply(x, gw, gb, res, mask, (G, eps, _ACT[act], slope, mask_scale))
+
+
+# ----------------------------------------------------------------------------------------------- FiLM / second-design FiLM
+class _Film(Function):
+    """grc_lora.py:108-129 (the condition is already cat/pad/truncated by FiLMLayer.condition)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, proj_w, proj_b, feature_dim):
+        cond_t = ops.cast(cond, x.dtype)
+        proj = ops.linear(cond_t, _w(proj_w, x), _w(proj_b, x))
+        y = ops.film(x, proj, feature_dim)
+        ctx.F = feature_dim
+        ctx.save_for_backward(x, cond_t, proj, proj_w, proj_b, cond)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, cond_t, proj, proj_w, proj_b, cond = ctx.saved_tensors
+        gx, gproj = ops.film_bwd(x, gy, proj, ctx.F)
+        gcond, gwp, gbp = ops.linear_bwd(cond_t, _w(proj_w, x), gproj, need_gx=ctx.needs_input_grad[1])
+        return gx, (_to(gcond, cond) if gcond is not None else None), _to(gwp, proj_w), _to(gbp, proj_b), None
 
 
 def film(x, cond, proj_w, proj_b, feature_dim):
-    """grc_lora.py:108-129 (the condition is already cat/pad/truncated by FiLMLayer.condition)."""
-    with torch.no_grad():
-        proj = ops.linear(ops.cast(cond, x.dtype), _w(proj_w, x), _w(proj_b, x))
-        y = ops.film(x, proj, feature_dim)
-    return _track("film", y, x, cond, proj_w, proj_b)
+    return _Film.apply(x, cond, proj_w, proj_b, feature_dim)
 
 
 def film2(x, spk, emo, scale_w, scale_b, shift_w, shift_b):
-    """generator.py:187-199: (W_s e + b_s) * x + (W_h e + b_h), e = spk + emo."""
+    """generator.py:187-199: (W_s e + b_s) * x + (W_h e + b_h), e = spk + emo.  Forward only."""
     with torch.no_grad():
         e = ops.act(ops.cast(spk, x.dtype), N.ACT_NONE, res=ops.cast(emo, x.dtype))
         scale = ops.linear(e, _w(scale_w, x), _w(scale_b, x))
@@ -95,69 +250,102 @@ def film2(x, spk, emo, scale_w, scale_b, shift_w, shift_b):
 
 
 # ----------------------------------------------------------------------------------------------- GRC + LoRA / MRF (generic shapes)
-def _grc_forward_into(x, blk, out, off):
+class _GrcFold(Function):
+    """Parameter algebra of grc_lora.py:33-57 folded to (w_eff, b_eff); computed in the parameters' dtype."""
+
+    @staticmethod
+    def forward(ctx, conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w, proj_b, groups):
+        w_eff, b_eff = ops.grc_fold_weights(conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w, proj_b, groups)
+        ctx.groups = groups
+        ctx.save_for_backward(conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w)
+        return w_eff, b_eff
+
+    @staticmethod
+    def backward(ctx, g_weff, g_beff):
+        conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w = ctx.saved_tensors
+        g_weff = ops.cast(g_weff.contiguous(), torch.float32)
+        g_beff = ops.cast(g_beff.contiguous(), torch.float32)
+        gs = ops.grc_fold_bwd(g_weff, g_beff, conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w, ctx.groups)
+        ps = (conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w)
+        out = [_to(g, p) for g, p in zip(gs[:6], ps)]
+        return (*out, _to(gs[6], conv_b), None)
+
+
+class _Cat(Function):
+    """torch.cat along channels (grc_lora.py:159) as strided copies."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, T = xs[0].shape[0], xs[0].shape[2]
+        ctx.sizes = [x.shape[1] for x in xs]
+        out = torch.empty(B, sum(ctx.sizes), T, device=xs[0].device, dtype=xs[0].dtype)
+        off = 0
+        for x in xs:
+            ops.copy_rows(x if x.stride(2) == 1 else x.contiguous(), out[:, off:off + x.shape[1]])
+            off += x.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.sizes:
+            o = torch.empty(g.shape[0], c, g.shape[2], device=g.device, dtype=g.dtype)
+            ops.copy_rows(g[:, off:off + c], o)
+            outs.append(o)
+            off += c
+        return tuple(outs)
+
+
+def _grc_generic(x, blk):
     """grc_lora.py:32-68 with the parameter algebra folded: conv_g + LoRA + 1x1 -> one dense dilated conv."""
     k, d = blk.kernel_size, blk.dilation
     if k % 2 == 0:
         raise RuntimeError("GRC_LoRA_Block: even kernel sizes make base/LoRA lengths differ (as in the reference)")
-    w_eff, b_eff = ops.grc_fold_weights(_w(blk.conv.weight, x), _w(blk.conv.bias, x), _w(blk.lora_A, x),
-                                        _w(blk.lora_B, x), _w(blk.lora_scaling, x),
-                                        _w(blk.output_projection.weight, x), _w(blk.output_projection.bias, x),
-                                        blk.groups)
-    v = ops.conv1d(x, w_eff, b_eff, None, 1, (k - 1) * d // 2, d, 1)
-    mean, rstd = ops.groupnorm_stats(v, blk.norm_groups, blk.norm.eps)
-    C = blk.out_channels
-    ysl = out[:, off:off + C]
-    if blk.in_channels != C:
-        ops.conv1d(x, _w(blk.residual_proj.weight, x), _w(blk.residual_proj.bias, x), out=out, out_channel_offset=off)
-        res = ysl
+    w_eff, b_eff = _GrcFold.apply(blk.conv.weight, blk.conv.bias, blk.lora_A, blk.lora_B, blk.lora_scaling,
+                                  blk.output_projection.weight, blk.output_projection.bias, blk.groups)
+    v = conv1d(x, w_eff, b_eff, padding=(k - 1) * d // 2, dilation=d)
+    if blk.in_channels != blk.out_channels:
+        res = conv1d(x, blk.residual_proj.weight, blk.residual_proj.bias)
     else:
         res = x
-    ops.groupnorm_apply(v, mean, rstd, _w(blk.norm.weight, x), _w(blk.norm.bias, x), blk.norm_groups,
-                        act=N.ACT_SILU, res=res, out=ysl)
+    return group_norm(v, blk.norm.weight, blk.norm.bias, blk.norm_groups, blk.norm.eps, act="silu", res=res)
 
 
 def grc_lora_block(x, blk, out=None, out_channel_offset=0):
-    with torch.no_grad():
-        x = x if x.stride(2) == 1 else x.contiguous()
-        if out is None:
-            out = torch.empty(x.shape[0], blk.out_channels, x.shape[2], device=x.device, dtype=x.dtype)
-            out_channel_offset = 0
-        _grc_forward_into(x, blk, out, out_channel_offset)
-    return _track("grc_lora_block", out, x, *blk.parameters())
+    return _grc_generic(x if x.stride(2) == 1 else x.contiguous(), blk)
 
 
-def mrf_block(x, blk, force_generic=False):
-    """grc_lora.py:157-163.  64-channel blocks of the generator's shape run the fused MFMA kernel
-    (csrc/mrf_fused.hip) in channels-last layout; any other shape runs the generic kernels, where the
-    three branches write straight into the channel slices of the concat buffer (no torch.cat copy)."""
+def dropout_mask(shape, p, device):
+    """uint8 keep-mask of nn.Dropout(p) (grc_lora.py:151,162); drawn from torch's Philox stream of this rank."""
+    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+
+
+def mrf_block(x, blk, force_generic=False, mask=None):
+    """grc_lora.py:157-163.  Inference on 64-channel blocks of the generator's shape runs the fused MFMA kernel
+    (csrc/mrf_fused.hip) in channels-last layout; training and any other shape run the generic differentiable path."""
     from .fused import mrf_fused_for
-    fz = None if force_generic else mrf_fused_for(blk)
-    if fz is not None and not (blk.training and blk.dropout.p > 0):
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in blk.parameters()))
+    training_dropout = blk.training and blk.dropout.p > 0
+    fz = None if (force_generic or needs_grad or training_dropout) else mrf_fused_for(blk)
+    if fz is not None:
         with torch.no_grad():
-            y = ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
-        return _track("mrf_block", y, x, *blk.parameters())
-    with torch.no_grad():
-        x = x if x.is_contiguous() else x.contiguous()
-        B, C, T = x.shape
-        cpd, n = blk.channels_per_dilation, len(blk.dilations)
-        cat = torch.empty(B, cpd * n, T, device=x.device, dtype=x.dtype)
-        for i, g in enumerate(blk.conv_layers):
-            _grc_forward_into(x, g, cat, i * cpd)
-        f = ops.conv1d(cat, _w(blk.fusion.weight, x), _w(blk.fusion.bias, x))
-        mean, rstd = ops.groupnorm_stats(f, blk.norm_groups, blk.norm.eps)
-        mask, scale = None, 1.0
-        p = blk.dropout.p
-        if blk.training and p > 0:
-            mask = (torch.rand(f.shape, device=x.device) >= p).to(torch.uint8)  # TODO(philox kernel)
-            scale = 1.0 / (1.0 - p)
-        y = ops.groupnorm_apply(f, mean, rstd, _w(blk.norm.weight, x), _w(blk.norm.bias, x), blk.norm_groups,
-                                res=x, mask=mask, mask_scale=scale)
-    return _track("mrf_block", y, x, *blk.parameters())
+            return ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
+    x = x if x.is_contiguous() else x.contiguous()
+    branches = [_grc_generic(x, g) for g in blk.conv_layers]
+    cat = _Cat.apply(*branches)
+    f = conv1d(cat, blk.fusion.weight, blk.fusion.bias)
+    scale, p = 1.0, blk.dropout.p
+    if training_dropout:
+        if mask is None:
+            mask = dropout_mask(f.shape, p, x.device)
+        scale = 1.0 / (1.0 - p)
+    else:
+        mask = None
+    return group_norm(f, blk.norm.weight, blk.norm.bias, blk.norm_groups, blk.norm.eps, res=x, mask=mask, mask_scale=scale)
 
 
 def grouped_residual_conv1d(x, blk):
-    """generator.py:141-172: LeakyReLU(GN_G(Conv1x1(conv_g(x) + alpha*LoRA_g(x)) + x))."""
+    """generator.py:141-172: LeakyReLU(GN_G(Conv1x1(conv_g(x) + alpha*LoRA_g(x)) + x)).  Forward only."""
     with torch.no_grad():
         x = x if x.is_contiguous() else x.contiguous()
         G, C = blk.groups, blk.channels
@@ -177,24 +365,132 @@ def grouped_residual_conv1d(x, blk):
 
 
 # ----------------------------------------------------------------------------------------------- discriminators
+class _AvgPool(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s, ctx.T = s, x.shape[2]
+        return ops.avgpool1d(x, s)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.avgpool1d_bwd(gy, ctx.T, ctx.s), None
+
+
+class _MpdFold(Function):
+    """discriminators.py:72-79: zero right-pad + view(B,C,period,T'/period)."""
+
+    @staticmethod
+    def forward(ctx, x, period):
+        ctx.T = x.shape[2]
+        return ops.mpd_fold(x, period)
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, C = gy.shape[0], gy.shape[1]
+        g = gy.contiguous().view(B, C, -1)
+        if g.shape[2] == ctx.T:
+            return g, None
+        gx = torch.empty(B, C, ctx.T, device=gy.device, dtype=gy.dtype)
+        ops.copy_rows(g, gx)
+        return gx, None
+
+
 def _convs(seq):
     return [seq[i] for i in (0, 2, 4, 6, 8)]
 
 
 def disc2d(x, blk):
     """discriminators.py:68-84."""
-    with torch.no_grad():
-        h = ops.mpd_fold(x, blk.period)
-        for li, conv in enumerate(_convs(blk.conv_layers)):
-            h = ops.conv2d(h, _w(conv.weight, x), _w(conv.bias, x), (1, 1), N.ACT_LRELU if li < 4 else N.ACT_NONE, 0.1)
-    return _track("disc2d", h, x, *blk.parameters())
+    B, C, T = x.shape
+    if T % blk.period == 0:
+        h = x.contiguous().view(B, C, blk.period, T // blk.period)   # exact multiple: the fold is a pure view
+    else:
+        h = _MpdFold.apply(x, blk.period)
+    for li, conv in enumerate(_convs(blk.conv_layers)):
+        h = conv2d(h, conv.weight, conv.bias, (1, 1), "lrelu" if li < 4 else None, 0.1)
+    return h
 
 
 def disc1d(x, blk):
     """discriminators.py:109-117."""
+    h = _AvgPool.apply(x, blk.scale) if blk.scale > 1 else x
+    for li, conv in enumerate(_convs(blk.conv_layers)):
+        h = conv1d(h, conv.weight, conv.bias, padding=7, act="lrelu" if li < 4 else None, slope=0.1)
+    return h
+
+
+# ----------------------------------------------------------------------------------------------- losses
+class _Loss(Function):
+    """weight * mean-reduced loss, value and gradient from one HIP pass (csrc/train.hip loss_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, y, kind, c, weight):
+        need_gy = y is not None and y.requires_grad
+        acc, gx, gyt = ops.loss_fwd_bwd(x, y, kind, c, weight, want_gx=True, want_gy=need_gy)
+        ctx.save_for_backward(gx, gyt)
+        return acc.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gx, gyt = ctx.saved_tensors
+        gdev = g.reshape(1).float()
+        gx = ops.scale_(gx.clone(), 1.0, gdev)
+        if gyt is not None:
+            gyt = ops.scale_(gyt.clone(), 1.0, gdev)
+        return gx, gyt, None, None, None
+
+
+def mse_const(x, c, weight=1.0):
+    """mean((x - c)^2): F.mse_loss(x, ones/zeros) of complete_vocoder.py:104,157-158."""
+    return _Loss.apply(x, None, 0, float(c), float(weight))
+
+
+def l1(x, y, weight=1.0):
+    """mean|x - y|: F.l1_loss of complete_vocoder.py:118,127."""
+    return _Loss.apply(x, y, 1, 0.0, float(weight))
+
+
+def mse(x, y, weight=1.0):
+    return _Loss.apply(x, y, 4, 0.0, float(weight))
+
+
+def hinge_g(x, weight=1.0):
+    """mean(relu(1 - x)): conditioned_hifigan.py:263."""
+    return _Loss.apply(x, None, 2, 0.0, float(weight))
+
+
+def hinge_d_fake(x, weight=1.0):
+    """mean(relu(1 + x)): conditioned_hifigan.py:265."""
+    return _Loss.apply(x, None, 3, 0.0, float(weight))
+
+
+class _MelL1(Function):
+    """weight * mean |logmel(wave) - target| (kind 0) or mean squared (kind 1); defined by this build."""
+
+    @staticmethod
+    def forward(ctx, wave, target, fb, n_fft, hop, clampv, weight, kind):
+        acc, _, gwave = ops.mel_loss(wave, fb, target, n_fft, hop, clampv, weight, backward=wave.requires_grad, kind=kind)
+        ctx.save_for_backward(gwave)
+        ctx.dtype = wave.dtype
+        return acc.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (gwave,) = ctx.saved_tensors
+        gw = ops.scale_(gwave.clone(), 1.0, g.reshape(1).float())
+        return (gw if ctx.dtype == torch.float32 else ops.cast(gw, ctx.dtype)), None, None, None, None, None, None, None
+
+
+def mel_l1(wave, target, fb, n_fft=1024, hop=256, clampv=1e-5, weight=1.0):
+    return _MelL1.apply(wave, target, fb, n_fft, hop, clampv, float(weight), 0)
+
+
+def mel_mse(wave, target, fb, n_fft=1024, hop=256, clampv=1e-5, weight=1.0):
+    """weight * mean (logmel(wave) - target)^2: the MSE mel term of conditioned_hifigan.py:238."""
+    return _MelL1.apply(wave, target, fb, n_fft, hop, clampv, float(weight), 1)
+
+
+def mel_spectrogram(wave, fb, n_fft=1024, hop=256, clampv=1e-5):
+    """log-mel [B, n_mels, T/hop] (fp32) of a waveform [B,1,T]."""
     with torch.no_grad():
-        h = ops.avgpool1d(x, blk.scale) if blk.scale > 1 else x
-        for li, conv in enumerate(_convs(blk.conv_layers)):
-            h = ops.conv1d(h, _w(conv.weight, x), _w(conv.bias, x), None, 1, 7, 1, 1,
-                           N.ACT_LRELU if li < 4 else N.ACT_NONE, 0.1)
-    return _track("disc1d", h, x, *blk.parameters())
+        return ops.mel_loss(wave, fb, None, n_fft, hop, clampv, 1.0, backward=False, want_mel=True)[1]

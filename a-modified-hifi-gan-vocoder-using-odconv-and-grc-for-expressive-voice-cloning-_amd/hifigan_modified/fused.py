@@ -16,7 +16,7 @@ _INT3 = ctypes.c_int * 3
 
 
 def _versions(params):
-    return tuple((id(p), p._version, p.data_ptr()) for p in params)
+    return (ops.param_epoch(),) + tuple((id(p), p._version, p.data_ptr()) for p in params)
 
 
 class MrfFused:
@@ -131,7 +131,7 @@ class OdconvFused:
 
     def packed(self, dtype, device):
         w = self.mod.kernels
-        ver = (w._version, w.data_ptr())
+        ver = (w._version, w.data_ptr(), ops.param_epoch())
         hit = self._packed.get(dtype)
         if hit is not None and hit[0] == ver and hit[1].device == device:
             return hit[1]
@@ -186,7 +186,7 @@ class GeneratorFused:
 
     def out_weights(self, device):
         w, b = self.gen.output_proj.weight, self.gen.output_proj.bias
-        ver = (w._version, w.data_ptr(), b._version)
+        ver = (w._version, w.data_ptr(), b._version, ops.param_epoch())
         hit = self._wt.get("w")
         if hit is not None and hit[0] == ver and hit[1].device == device:
             return hit[1], hit[2]

@@ -54,6 +54,19 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return y
 
 
+_EPOCH = [0]
+
+
+def bump_param_epoch():
+    """Called by optimizers that update parameters in place behind torch's back (flat-arena AdamW): invalidates
+    every cached cast / packed weight."""
+    _EPOCH[0] += 1
+
+
+def param_epoch():
+    return _EPOCH[0]
+
+
 class _ParamCache:
     """Casts of parameters to the activation dtype.  An entry is valid only for the very same tensor
     object (weak reference - ids are recycled once a module is freed) at the same ``_version``, so an
@@ -69,12 +82,12 @@ class _ParamCache:
             return p.detach()
         key = (id(p), dtype)
         hit = self._d.get(key)
-        if hit is not None and hit[0]() is p and hit[1] == p._version and hit[2].device == p.device:
+        if hit is not None and hit[0]() is p and hit[1] == (p._version, _EPOCH[0]) and hit[2].device == p.device:
             return hit[2]
         v = cast(p.detach(), dtype)
         if len(self._d) > 4096:  # drop entries whose parameter is gone
             self._d = {k: e for k, e in self._d.items() if e[0]() is not None}
-        self._d[key] = (weakref.ref(p), p._version, v)
+        self._d[key] = (weakref.ref(p), (p._version, _EPOCH[0]), v)
         return v
 
 
@@ -264,3 +277,162 @@ def ntc_to_nct(x):
     y = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
     N.call("mv_ntc_to_nct", _p(x), _p(y), B, C, T, _dt(x), _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------ backward / training ops
+def _f32(*shape, device):
+    return torch.empty(*shape, device=device, dtype=torch.float32)
+
+
+def act_bwd(gy, y, kind, slope=0.1):
+    gy, y = _c(gy), _c(y)
+    gx = torch.empty_like(gy)
+    N.call("mv_act_bwd", _p(gy), _p(y), _p(gx), gy.numel(), kind, float(slope), _dt(gy), _stream())
+    return gx
+
+
+def conv1d_wgrad(x, gy, w, alpha, ks, stride, padding, dilation):
+    """x [B,Cin,Tin], gy [B,Cout,Tout] -> gw fp32 [nb?,Cout,Cin,ks] (+ galpha fp32 [B,nb] when alpha is given)."""
+    B, Cin, Tin = x.shape
+    _, Cout, Tout = gy.shape
+    assert x.stride(2) == 1 and gy.stride(2) == 1
+    nb = 1 if alpha is None else alpha.shape[1]
+    gw = _f32(*((nb, Cout, Cin, ks) if alpha is not None else (Cout, Cin, ks)), device=x.device)
+    galpha = torch.zeros(B, nb, device=x.device, dtype=torch.float32) if alpha is not None else None
+    N.call("mv_conv1d_wgrad", _p(x), _p(gy), _p(_c(w)) if w is not None else None, _p(alpha), _p(gw), _p(galpha),
+           B, Cin, Tin, Cout, Tout, ks, stride, padding, dilation, nb, x.stride(0), x.stride(1), gy.stride(0), gy.stride(1),
+           _dt(x), _stream())
+    return gw, galpha
+
+
+def bias_grad(gy, alpha=None, bias=None, galpha=None):
+    """gy [B,C,T] (or [B,C,H,W] flattened by the caller) -> gbias fp32 [K,C] / [C]; adds the bias term to galpha."""
+    B, C, T = gy.shape
+    assert gy.stride(2) == 1
+    K = 1 if alpha is None else alpha.shape[1]
+    ws = _f32(B * C, device=gy.device)
+    gb = _f32(K, C, device=gy.device)
+    N.call("mv_bias_grad", _p(gy), _p(alpha), _p(_c(bias)) if bias is not None else None, _p(ws), _p(gb), _p(galpha),
+           B, C, T, K, gy.stride(0), gy.stride(1), _dt(gy), _stream())
+    return gb if alpha is not None else gb[0]
+
+
+def odconv_attn_bwd(alpha, galpha, pooled, wa, T):
+    B, K = alpha.shape
+    C = pooled.shape[1]
+    gwa, gba, gm = _f32(K, C, device=alpha.device), _f32(K, device=alpha.device), _f32(B, C, device=alpha.device)
+    N.call("mv_odconv_attn_bwd", _p(alpha), _p(galpha), _p(pooled), _p(_c(wa)), _p(gwa), _p(gba), _p(gm), B, C, T, K,
+           _dt(wa), _stream())
+    return gwa, gba, gm
+
+
+def add_rowconst_(x, v):
+    B, C, T = x.shape
+    assert x.is_contiguous()
+    N.call("mv_add_rowconst", _p(x), _p(v), B * C, T, _dt(x), _stream())
+    return x
+
+
+def groupnorm_bwd(x, gy, mean, rstd, gw, gb, G, act=N.ACT_NONE, slope=0.1, mask=None, mask_scale=1.0):
+    B, C, T = x.shape
+    assert x.stride(2) == 1 and gy.stride(2) == 1
+    gz = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
+    ws = _f32(2 * B * G + 2 * B * C, device=x.device)
+    gx = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
+    dgw, dgb = _f32(C, device=x.device), _f32(C, device=x.device)
+    N.call("mv_groupnorm_bwd", _p(x), _p(gy), _p(mean), _p(rstd), _p(_c(gw)), _p(_c(gb)), _p(mask), float(mask_scale),
+           act, float(slope), _p(gz), _p(ws), _p(gx), _p(dgw), _p(dgb), B, C, T, G, x.stride(0), x.stride(1),
+           gy.stride(0), gy.stride(1), _dt(x), _stream())
+    return gx, dgw, dgb
+
+
+def film_bwd(x, gy, proj, F):
+    x, gy = _c(x), _c(gy)
+    B, C, T = x.shape
+    gx = torch.empty_like(x)
+    gproj = _f32(B, 2 * F, device=x.device)
+    N.call("mv_film_bwd", _p(x), _p(gy), _p(_c(proj)), _p(gx), _p(gproj), B, C, T, F, _dt(x), _stream())
+    return gx, gproj
+
+
+def linear_bwd(x, w, gy32, need_gx=True):
+    x = _c(x)
+    M, Kd = x.shape
+    Nn = w.shape[0]
+    gx = _f32(M, Kd, device=x.device) if need_gx else None
+    gw, gb = _f32(Nn, Kd, device=x.device), _f32(Nn, device=x.device)
+    N.call("mv_linear_bwd", _p(x), _p(_c(w)), _p(_c(gy32)), _p(gx), _p(gw), _p(gb), M, Nn, Kd, _dt(x), _stream())
+    return gx, gw, gb
+
+
+def avgpool1d_bwd(gy, T, s):
+    gy = _c(gy)
+    B, C, To = gy.shape
+    gx = torch.empty(B, C, T, device=gy.device, dtype=gy.dtype)
+    N.call("mv_avgpool1d_bwd", _p(gy), _p(gx), B * C, T, s, _dt(gy), _stream())
+    return gx
+
+
+def copy_rows(src, dst):
+    """dst[b, c, :n] = src[b, c, :n] for 3-D tensors with unit inner stride (channel concat / slice / fold backward)."""
+    B, C, n = src.shape[0], src.shape[1], min(src.shape[2], dst.shape[2])
+    assert src.stride(2) == 1 and dst.stride(2) == 1 and dst.shape[0] == B and dst.shape[1] == C
+    N.call("mv_copy2d", _p(src), _p(dst), n, B, C, src.stride(0), src.stride(1), dst.stride(0), dst.stride(1), _dt(src), _stream())
+    return dst
+
+
+def conv2d_flip_weights(w):
+    w = _c(w)
+    Cout, Cin, kh, kw = w.shape
+    wt = torch.empty(Cin, Cout, kh, kw, device=w.device, dtype=w.dtype)
+    N.call("mv_conv2d_flip_weights", _p(w), _p(wt), Cout, Cin, kh, kw, _dt(w), _stream())
+    return wt
+
+
+def conv2d_wgrad(x, gy, kh, kw, ph, pw):
+    x, gy = _c(x), _c(gy)
+    B, Cin, H, W = x.shape
+    Cout = gy.shape[1]
+    gw = _f32(Cout, Cin, kh, kw, device=x.device)
+    N.call("mv_conv2d_wgrad", _p(x), _p(gy), _p(gw), B, Cin, H, W, Cout, kh, kw, ph, pw, _dt(x), _stream())
+    return gw
+
+
+def grc_fold_bwd(g_weff, g_beff, conv_w, conv_b, lora_A, lora_B, lora_scaling, proj_w, groups):
+    Cout, cin_g, ks = conv_w.shape
+    Cin, rank, dev = cin_g * groups, lora_A.shape[1], conv_w.device
+    outs = [_f32(*s, device=dev) for s in ((Cout, cin_g, ks), (Cout,), (Cin, rank), (rank, Cout), (1,), (Cout, Cout, 1), (Cout,))]
+    N.call("mv_grc_fold_bwd", _p(_c(g_weff)), _p(_c(g_beff)), _p(_c(conv_w)), _p(_c(conv_b)), _p(_c(lora_A)), _p(_c(lora_B)),
+           _p(_c(lora_scaling)), _p(_c(proj_w)), *[_p(o) for o in outs], Cin, Cout, ks, groups, rank, _dt(conv_w), _stream())
+    return outs
+
+
+def loss_fwd_bwd(x, y, kind, c=0.0, weight=1.0, want_gx=True, want_gy=False, acc=None):
+    """Returns (loss_acc fp32 [1], gx, gy).  acc: existing accumulator to add into."""
+    x = _c(x)
+    y = _c(y)
+    if acc is None:
+        acc = torch.zeros(1, device=x.device, dtype=torch.float32)
+    gx = torch.empty_like(x) if want_gx else None
+    gyt = torch.empty_like(x) if want_gy else None
+    N.call("mv_loss_fwd_bwd", _p(x), _p(y), float(c), float(weight), _p(acc), _p(gx), _p(gyt), x.numel(), kind, _dt(x), _stream())
+    return acc, gx, gyt
+
+
+def scale_(x, factor=1.0, factor_dev=None):
+    assert x.is_contiguous()
+    N.call("mv_scale", _p(x), _p(factor_dev), float(factor), x.numel(), _dt(x), _stream())
+    return x
+
+
+def mel_loss(wave, fb, target=None, n_fft=1024, hop=256, clampv=1e-5, weight=1.0, backward=False, want_mel=False,
+             kind=0):
+    wave = _c(wave)
+    B, _, T = wave.shape
+    n_mels = fb.shape[0]
+    acc = torch.zeros(1, device=wave.device, dtype=torch.float32)
+    mel = _f32(B, n_mels, T // hop, device=wave.device) if want_mel else None
+    gwave = torch.zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None
+    N.call("mv_mel_loss", _p(wave), _p(fb), _p(_c(target)), _p(mel), _p(acc), _p(gwave), B, T, n_fft, hop, n_mels,
+           float(clampv), float(weight), int(kind), int(backward), _dt(wave), _stream())
+    return acc, mel, gwave

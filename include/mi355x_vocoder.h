@@ -178,6 +178,86 @@ int mv_conv_out_pack(const void* w, int param_dtype, float* wt, int C, int ks, v
 int mv_conv_out_act_cl(const void* x, const float* wt, float bias, void* y, int B, int T, int C, int ks, int pad,
                        int act, int dtype, void* stream);
 
+/* ================================================================================================
+ * Backward / training entry points.  Parameter gradients are always fp32.  Data gradients of the convolutions
+ * re-use the forward entry points: dgrad(conv1d) = mv_conv_transpose1d_fwd(gy, same weights), dgrad(conv_transpose1d)
+ * = mv_conv1d_fwd(gy, same weights), dgrad(conv2d) = mv_conv2d_fwd(gy, mv_conv2d_flip_weights(w)).
+ * (autograd of F.conv1d / F.conv_transpose1d / F.conv2d at odconv.py:95-99,192-197, grc_lora.py:33,57,66,160,
+ *  discriminators.py:57-65,97-107) */
+
+/* gx = gy * act'(z), expressed through the activation OUTPUT y (LeakyReLU: sign(y); tanh: 1-y^2). */
+int mv_act_bwd(const void* gy, const void* y, void* gx, long n, int act, float slope, int dtype, void* stream);
+
+/* conv1d weight gradient (groups = 1, ks <= 16).  y = conv1d(x, w[nbanks][Cout][Cin][ks], alpha).
+ *   nbanks == 1: gw [Cout][Cin][ks] = sum_{b,t} gy x ;  nbanks > 1 (ODConv): gw[k] = sum_b alpha[b,k] gW~_b and
+ *   galpha[b,k] += <gW~_b, w[k]> (galpha must be zero- or bias-term-initialised by the caller; accumulated atomically).
+ *   The transposed-conv weight gradient is the same call with the roles swapped (x := gy, gy := x, Cin := Cout, ...):
+ *   see functional.py.  Strides as in mv_conv1d_fwd. */
+int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, const float* alpha, float* gw, float* galpha,
+                    int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int nbanks,
+                    long x_bs, long x_cs, long g_bs, long g_cs, int dtype, void* stream);
+/* gbias[k][o] = sum_b alpha[b,k] sum_t gy[b,o,t]; galpha[b,k] += sum_o (sum_t gy[b,o,t]) bias[k][o] (K > 1).
+ * rowsum_ws: fp32 [B*C] scratch. */
+int mv_bias_grad(const void* gy, const float* alpha, const void* bias, float* rowsum_ws, float* gbias, float* galpha,
+                 int B, int C, int T, int K, long g_bs, long g_cs, int dtype, void* stream);
+/* ODConv attention backward: from galpha to gWa [K][C], gba [K] and gm [B][C] = (1/T) Wa^T gz, the
+ * per-(b,c) constant that mv_add_rowconst adds to every time step of gx. */
+int mv_odconv_attn_bwd(const float* alpha, const float* galpha, const float* pooled, const void* wa, float* gwa,
+                       float* gba, float* gm, int B, int C, int T, int K, int dtype, void* stream);
+int mv_add_rowconst(void* x, const float* v, long rows, int T, int dtype, void* stream);
+
+/* GroupNorm(+activation, +dropout mask) backward.  y = act((x-mean)*rstd*gw+gb) * mask*mask_scale (+ res, whose gradient is gy).
+ *   gz_ws: B*C*T elements of `dtype`; ws: fp32 [2*B*G + 2*B*C]; dgw/dgb: fp32 [C] (may be NULL). */
+int mv_groupnorm_bwd(const void* x, const void* gy, const float* mean, const float* rstd, const void* gw, const void* gb,
+                     const uint8_t* mask, float mask_scale, int act, float slope, void* gz_ws, float* ws, void* gx,
+                     float* dgw, float* dgb, int B, int C, int T, int G, long x_bs, long x_cs, long g_bs, long g_cs,
+                     int dtype, void* stream);
+
+/* FiLM backward: gx = gy*gamma; gproj [B][2F] fp32 = (sum_t gy*x | sum_t gy).  Linear backward (fp32 gy [M][N]). */
+int mv_film_bwd(const void* x, const void* gy, const void* proj, void* gx, float* gproj, int B, int C, int T, int F,
+                int dtype, void* stream);
+int mv_linear_bwd(const void* x, const void* w, const float* gy, float* gx, float* gw, float* gb, int M, int N, int Kd,
+                  int dtype, void* stream);
+
+int mv_avgpool1d_bwd(const void* gy, void* gx, long rows, int T, int s, int dtype, void* stream);
+/* strided 2-D copy dst[outer][inner][0..n) = src[outer][inner][0..n) (element strides) - channel concat / slice. */
+int mv_copy2d(const void* src, void* dst, int n, int rows_outer, int rows_inner, long s_os, long s_rs, long d_os,
+              long d_rs, int dtype, void* stream);
+/* wt[c][o][kh-1-i][kw-1-j] = w[o][c][i][j] (conv2d data gradient = conv2d with these weights, same padding for odd kernels) */
+int mv_conv2d_flip_weights(const void* w, void* wt, int Cout, int Cin, int kh, int kw, int dtype, void* stream);
+int mv_conv2d_wgrad(const void* x, const void* gy, float* gw, int B, int Cin, int H, int W, int Cout, int kh, int kw,
+                    int ph, int pw, int dtype, void* stream);
+
+/* Backward of mv_grc_fold_weights: (g_weff, g_beff) fp32 -> fp32 gradients of the seven GRC parameter tensors. */
+int mv_grc_fold_bwd(const float* g_weff, const float* g_beff, const void* conv_w, const void* conv_b,
+                    const void* lora_A, const void* lora_B, const void* lora_scaling, const void* proj_w,
+                    float* g_conv_w, float* g_conv_b, float* g_A, float* g_B, float* g_s, float* g_proj_w,
+                    float* g_proj_b, int Cin, int Cout, int ks, int groups, int rank, int param_dtype, void* stream);
+
+/* Losses, value and gradient in one pass.   replaces complete_vocoder.py:103-127,156-176 and conditioned_hifigan.py:234-265
+ *   kind 0: mean((x-c)^2)  1: mean|x-y|  2: mean(relu(1-x))  3: mean(relu(1+x))  4: mean((x-y)^2)
+ *   loss_acc[0] += weight*value (fp32, atomic); gx (optional) = weight * d value/dx; gy (optional, kinds 1/4) = -gx. */
+int mv_loss_fwd_bwd(const void* x, const void* y, float c, float weight, float* loss_acc, void* gx, void* gy, long n,
+                    int kind, int dtype, void* stream);
+/* x *= factor * (factor_dev ? factor_dev[0] : 1) */
+int mv_scale(void* x, const float* factor_dev, float factor, long n, int dtype, void* stream);
+
+/* Log-mel spectrogram (+ L1 loss against `target` [B][n_mels][T/hop]) of wave [B][1][T]; defined by this build (the
+ * reference has only placeholders: complete_vocoder.py:210-212, conditioned_hifigan.py:269-274).  Frames: reflect pad
+ * (n_fft-hop)/2, periodic Hann, |rDFT|, mel = fb [n_mels][n_fft/2+1] (fp32) @ mag, log(max(., clamp)).
+ *   mel_out (optional fp32 [B][n_mels][T/hop]); loss_acc += weight * mean|logmel - target| (kind 0) or weight * mean (logmel - target)^2 (kind 1);
+ *   backward != 0: gwave (fp32 [B][T], zero on entry) += d loss / d wave. */
+int mv_mel_loss(const void* wave, const float* fb, const void* target, float* mel_out, float* loss_acc, float* gwave,
+                int B, int T, int n_fft, int hop, int n_mels, float clampv, float weight, int kind, int backward,
+                int dtype, void* stream);
+
+/* AdamW on a flat fp32 parameter arena (torch.optim.AdamW semantics; conditioned_hifigan.py:219): grads are first
+ * gathered into a flat fp32 buffer by mv_multi_gather (descs_dev: device array of {const void* src; long dst_off; long n;
+ * int dtype; int pad}; src == NULL -> zeros), which is also the buffer RCCL all-reduces. grad_scale multiplies g (1/world). */
+int mv_multi_gather(const void* descs_dev, int n_tensors, long max_len, float* flat, void* stream);
+int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
