@@ -1,0 +1,631 @@
+// Channels-last MFMA kernels for the discriminator stacks (the 99 % of a training step):
+//   Discriminator2D: 5x Conv2d 3x3 pad 1 (1-32-64-128-256-1) + LeakyReLU(0.1)   hifigan_modified/discriminators.py:56-66
+//   Discriminator1D: 5x Conv1d k15 pad 7 (same widths)      + LeakyReLU(0.1)   hifigan_modified/discriminators.py:97-107
+// Activations are [B][H][W][C] (H = period for MPD, 1 for MSD), stride 1, "same" padding.
+//
+//  dconv_cl_kernel   implicit GEMM  D[o][w] = sum_{(dh,dw,c)} Wp[o][(dh,dw,c)] X[h+dh][w+dw][c]  for one output row
+//                    segment; A = packed weights straight from L2 (prefetched one k-step ahead), B = kh input planes
+//                    staged in LDS.  Forward: + bias, LeakyReLU.  Data gradient: the same kernel on flipped/transposed
+//                    weights, its epilogue multiplies by LeakyReLU'(saved activation) so the result is already the
+//                    gradient w.r.t. the previous layer's pre-activation.
+//  dconv_head_*      the 256 -> 1 layer (forward dot, data-gradient outer product, weight-gradient reduction).
+//  dconv_wgrad_kernel  gW[o][(tap,c)] = sum_pos g[pos][o] x[pos+tap][c]: a GEMM whose contraction index is TIME, so both
+//                    operands are read from channels-last LDS tiles with ds_read_b64_tr_b16 (hardware transpose);
+//                    position chunks are spread over workgroups and summed with fp32 atomics.
+#include "mfma.h"
+
+namespace mv {
+
+struct DcP {
+  int B, H, W, Cin, Cout, kh, kw, act;
+  float slope;
+  int ksteps, cin32;
+};
+
+// packed[mt][kstep][lane][8]: row o = 16*mt + lane&15, k-chunk = 4*kstep + lane>>4 -> tap = chunk / (Cin/8), c = 8*(chunk % (Cin/8)) + j
+// flip == 0: forward weights  w[o][c][ih][iw]  (tap = ih*kw + iw)
+// flip == 1: data-gradient weights: rows = c (previous-layer channels), k runs over (flipped tap, o)
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void dconv_pack_kernel(const P* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
+                                                         int kh, int kw, int flip) {
+  const int M = flip ? Cin : Cout, Kc = flip ? Cout : Cin;
+  const int taps = kh * kw, cpc = Kc / 8, ksteps = taps * (Kc / 32);
+  const long total = (long)(M / 16) * ksteps * 512;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = idx % 8, lane = (idx / 8) % 64;
+    const long fr = idx / 512;
+    const int kstep = fr % ksteps, mt = fr / ksteps;
+    const int row = 16 * mt + (lane & 15), chunk = 4 * kstep + (lane >> 4);
+    const int tap = chunk / cpc, c = 8 * (chunk % cpc) + j;
+    float v;
+    if (!flip) v = ld<P>(w + ((long)row * Cin + c) * taps + tap);
+    else v = ld<P>(w + ((long)c * Cin + row) * taps + (taps - 1 - tap));   // w[o=c][cin=row][flipped tap]
+    st<T>(out + idx, v);
+  }
+}
+
+template <typename T, int MW, int NB>
+__global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                       const T* __restrict__ bias, const T* __restrict__ actsave,
+                                                       T* __restrict__ y, DcP p) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int ES = M::ES;
+  extern __shared__ __align__(16) char lds[];
+  const int RS = p.Cin * ES + 16;
+  const int prow = NB * 16 + p.kw - 1;          // staged columns per plane
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int w0 = blockIdx.x * NB * 16;
+  const int mt0 = (blockIdx.y * 4 + wid) * MW;
+  const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
+  const int n_mt = p.Cout / 16;
+  const int ph = p.kh / 2, pw = p.kw / 2;
+
+  // ---- stage kh input planes: rows h-ph..h+ph, columns w0-pw .. w0+NB*16+pw-1, zero outside the image
+  {
+    const int cpr = p.Cin * ES / 16;
+    const int per = prow * cpr;
+    for (int i = tid; i < p.kh * per; i += 256) {
+      const int pl = i / per, rem = i % per;
+      const int r = rem / cpr, ch = rem % cpr;
+      const int hh = h - ph + pl, ww = w0 - pw + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + (((long)b * p.H + hh) * p.W + ww) * p.Cin) + ch * 16);
+      *reinterpret_cast<u32x4*>(lds + ((long)pl * prow + r) * RS + ch * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[MW][NB];
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 16;
+  V a_cur[MW], a_nxt[MW];
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw) {
+    const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+    a_cur[mw] = M::load_b(wlane + ((long)mt * p.ksteps) * 1024);
+  }
+  int tap = 0, c32 = 0;
+  for (int kstep = 0; kstep < p.ksteps; ++kstep) {
+    if (kstep + 1 < p.ksteps) {
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw) {
+        const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+        a_nxt[mw] = M::load_b(wlane + ((long)mt * p.ksteps + kstep + 1) * 1024);
+      }
+    }
+    const int ih = tap / p.kw, iw = tap % p.kw;
+    const char* bbase = lds + ((long)ih * prow + iw + col) * RS + (c32 * 32 + 8 * g) * ES;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const V bf = M::load_b(bbase + (long)(n * 16) * RS);
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(a_cur[mw], bf, acc[mw][n]);
+    }
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) a_cur[mw] = a_nxt[mw];
+    if (++c32 == p.cin32) { c32 = 0; ++tap; }
+  }
+
+  // ---- epilogue through LDS: [w][rows of this workgroup] -> whole-row stores
+  __syncthreads();
+  constexpr int RW = 4 * MW * 16;
+  constexpr int ORS = RW * ES + 16;
+  const int R0 = blockIdx.y * RW;
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw) {
+    const int mt = mt0 + mw;
+    if (mt < n_mt) {
+      const int row = 16 * mt + 4 * g;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = ld<T>(bias + row + i);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        float ov[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = apply_act(acc[mw][n][i] + bv[i], p.act, p.slope);
+        M::store4(lds + (long)(n * 16 + col) * ORS + (row - R0) * ES, ov);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int EPC = 16 / ES;
+    constexpr int CPR = RW / EPC;
+    T* yrow = y + (((long)b * p.H + h) * p.W) * p.Cout;
+    const T* srow = actsave ? actsave + (((long)b * p.H + h) * p.W) * p.Cout : nullptr;
+    for (int i = tid; i < NB * 16 * CPR; i += 256) {
+      const int ch = i % CPR, wi = i / CPR;
+      const int ww = w0 + wi, row = R0 + ch * EPC;
+      if (ww >= p.W || row >= p.Cout) continue;
+      u32x4 val = *reinterpret_cast<const u32x4*>(lds + (long)wi * ORS + ch * 16);
+      if (srow) {   // data-gradient mode: multiply by LeakyReLU'(pre-activation) = (saved activation >= 0 ? 1 : slope)
+        float gvals[16 / ES], svals[16 / ES];
+        T tmp[16 / ES];
+        *reinterpret_cast<u32x4*>(tmp) = val;
+        const u32x4 sv = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(srow + (long)ww * p.Cout + row));
+        T stmp[16 / ES];
+        *reinterpret_cast<u32x4*>(stmp) = sv;
+#pragma unroll
+        for (int e = 0; e < 16 / ES; ++e) {
+          gvals[e] = ld<T>(tmp + e);
+          svals[e] = ld<T>(stmp + e);
+          st<T>(tmp + e, svals[e] >= 0.f ? gvals[e] : gvals[e] * p.slope);
+        }
+        val = *reinterpret_cast<u32x4*>(tmp);
+      }
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(yrow + (long)ww * p.Cout + row)) = val;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 256 -> 1 head
+// forward: y[pos] = b + sum_{tap,c} w[tap][c] x[pos+tap][c]     (wt fp32 [taps][C])
+template <typename T>
+__global__ __launch_bounds__(256) void dhead_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wt, float bias,
+                                                        T* __restrict__ y, int H, int W, int C, int kh, int kw) {
+  // one wave per output position: lanes split the channels (C/64 each), taps looped
+  const int lane = threadIdx.x & 63;
+  const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long total = (long)gridDim.y * 0 + 0; (void)total;
+  const int b = blockIdx.y;
+  if (pos >= (long)H * W) return;
+  const int h = (int)(pos / W), w = (int)(pos % W);
+  const int ph = kh / 2, pw = kw / 2;
+  float acc = 0.f;
+  for (int ih = 0; ih < kh; ++ih) {
+    const int hh = h + ih - ph;
+    if (hh < 0 || hh >= H) continue;
+    for (int iw = 0; iw < kw; ++iw) {
+      const int ww = w + iw - pw;
+      if (ww < 0 || ww >= W) continue;
+      const T* xr = x + (((long)b * H + hh) * W + ww) * C;
+      const float* wr = wt + (ih * kw + iw) * C;
+      for (int c = lane; c < C; c += 64) acc += ld<T>(xr + c) * wr[c];
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) st<T>(y + (long)b * H * W + pos, acc + bias);
+}
+
+// data gradient of the head, fused with LeakyReLU' of the previous layer:
+// gx[pos][c] = lrelu'(xsave[pos][c]) * sum_tap w[tap][c] g[pos - tap]
+template <typename T>
+__global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ g, const float* __restrict__ wt,
+                                                          const T* __restrict__ xsave, T* __restrict__ gx, int H, int W,
+                                                          int C, int kh, int kw, float slope) {
+  const int b = blockIdx.y;
+  const int ph = kh / 2, pw = kw / 2;
+  const long npos = (long)H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npos * C; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long pos = i / C;
+    const int h = (int)(pos / W), w = (int)(pos % W);
+    float acc = 0.f;
+    for (int ih = 0; ih < kh; ++ih) {
+      const int hh = h - (ih - ph);
+      if (hh < 0 || hh >= H) continue;
+      for (int iw = 0; iw < kw; ++iw) {
+        const int ww = w - (iw - pw);
+        if (ww < 0 || ww >= W) continue;
+        acc += wt[(ih * kw + iw) * C + c] * ld<T>(g + (long)b * npos + (long)hh * W + ww);
+      }
+    }
+    const float s = ld<T>(xsave + ((long)b * npos + pos) * C + c);
+    st<T>(gx + ((long)b * npos + pos) * C + c, s >= 0.f ? acc : acc * slope);
+  }
+}
+
+// weight gradient of the head: gw[tap][c] = sum_{b,pos} g[pos] x[pos+tap][c]; gb = sum g.   (atomic across workgroups)
+template <typename T>
+__global__ __launch_bounds__(256) void dhead_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                          float* __restrict__ gw, float* __restrict__ gb, int H, int W,
+                                                          int C, int kh, int kw, int chunk) {
+  const int b = blockIdx.y, c = threadIdx.x;            // blockDim.x == C (256)
+  const int ph = kh / 2, pw = kw / 2;
+  const long npos = (long)H * W;
+  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < npos ? p0 + chunk : npos;
+  float gbs = 0.f;
+  for (int ih = 0; ih < kh; ++ih)
+    for (int iw = 0; iw < kw; ++iw) {
+      float acc = 0.f;
+      for (long pos = p0; pos < p1; ++pos) {
+        const int h = (int)(pos / W), w = (int)(pos % W);
+        const int hh = h + ih - ph, ww = w + iw - pw;
+        const float gv = ld<T>(g + (long)b * npos + pos);
+        if (ih == 0 && iw == 0 && c == 0) gbs += gv;
+        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+        acc += gv * ld<T>(x + (((long)b * H + hh) * W + ww) * C + c);
+      }
+      atomicAdd(gw + (ih * kw + iw) * C + c, acc);
+    }
+  if (c == 0) atomicAdd(gb, gbs);
+}
+
+// ------------------------------------------------------------------------------------------------ MFMA weight gradient
+// gw[o][tap][c] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
+// workgroup: 4 waves; wave w owns M-tile (o) = blockIdx.y*4 + w and NW 16-channel N-tiles starting at blockIdx.x*NW*16;
+// positions: row (b,h) = blockIdx.z / wsplit, column chunk (blockIdx.z % wsplit) * WT .. +WT
+template <typename T, int NW, int TAPS_H, int TAPS_W>
+__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                          float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
+                                                          int WT, int wsplit, int nchunks, int chunks_per_wg) {
+  static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
+  using M = Mma<T>;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  constexpr int TAPS = TAPS_H * TAPS_W;
+  constexpr int PH = TAPS_H / 2, PW = TAPS_W / 2;
+  extern __shared__ __align__(16) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;   // transposed-read lane roles (guide T10)
+  const int o0 = (blockIdx.y * 4) * 16;            // first output channel of the workgroup (64 channels)
+  const int c0 = blockIdx.x * NW * 16;             // first input channel of the workgroup (NW*16 channels)
+  constexpr int GC = 64;                           // g tile channels
+  const int XC = NW * 16;
+  const int GRS = GC * 2 + 8, XRS = XC * 2 + 8;    // row strides (bytes), multiples of 8
+  const int xcols = WT + TAPS_W - 1;
+  char* gl = lds;                                   // [WT][GC]
+  char* xl = lds + (size_t)WT * GRS;                // [TAPS_H][xcols][XC]
+
+  f32x4 acc[TAPS][NW];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int n = 0; n < NW; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* ga = gl + (size_t)(8 * grp + q) * GRS + (wid * 16 + 4 * pp) * 2;
+  const char* xa = xl + (size_t)(8 * grp + q) * XRS + (4 * pp) * 2;
+
+  for (int ci = 0; ci < chunks_per_wg; ++ci) {
+  const int chunk = blockIdx.z * chunks_per_wg + ci;
+  if (chunk >= nchunks) break;                       // uniform across the workgroup
+  const int bh = chunk / wsplit, wc = chunk % wsplit;
+  const int b = bh / H, h = bh % H;
+  const int w0 = wc * WT;
+  if (ci) __syncthreads();                           // previous chunk's reads are done before restaging
+  // stage g tile (positions w0..w0+WT-1, channels o0..o0+63) and x planes (rows h-PH.., cols w0-PW.., channels c0..)
+  for (int i = tid; i < WT * (GC / 4); i += 256) {
+    const int r = i / (GC / 4), ch = i % (GC / 4);
+    const int ww = w0 + r;
+    u32x2 v = {0u, 0u};
+    if (ww < W && o0 + ch * 4 < Cout)
+      v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(g + (((long)b * H + h) * W + ww) * Cout + o0) + ch * 8);
+    *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 8) = v;
+  }
+  for (int i = tid; i < TAPS_H * xcols * (XC / 4); i += 256) {
+    const int ch = i % (XC / 4), r = (i / (XC / 4)) % xcols, pl = i / ((XC / 4) * xcols);
+    const int hh = h - PH + pl, ww = w0 - PW + r;
+    u32x2 v = {0u, 0u};
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+      v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(x + (((long)b * H + hh) * W + ww) * Cin + c0) + ch * 8);
+    *reinterpret_cast<u32x2*>(xl + ((size_t)pl * xcols + r) * XRS + ch * 8) = v;
+  }
+  __syncthreads();
+
+  // A[row o][k = pos]: transposed read of the g tile: block rows = positions (k), columns = 16 channels of this wave's M-tile
+  // lane (4q+pp) of group grp supplies the address of block row q, columns 4pp..4pp+3; MFMA k index of the lane = 8*grp + j
+  for (int k0 = 0; k0 < WT; k0 += 32) {
+    typename M::V a;
+    {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ga + (size_t)k0 * GRS));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ga + (size_t)(k0 + 4) * GRS));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      a.v = __builtin_bit_cast(decltype(a.v), both);
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int ih = t / TAPS_W, iw = t % TAPS_W;
+#pragma unroll
+      for (int n = 0; n < NW; ++n) {
+        const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS + n * 32;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)pb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * XRS));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        typename M::V bfr;
+        bfr.v = __builtin_bit_cast(decltype(bfr.v), both);
+        acc[t][n] = M::mma(a, bfr, acc[t][n]);
+      }
+    }
+  }
+  }  // chunk loop
+  // D[row = o (4*grp + r)][col = c (li)] -> gw[o][c][tap]  (reference layout [Cout][Cin][kh][kw])
+  const int o = o0 + wid * 16 + 4 * grp;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int n = 0; n < NW; ++n) {
+      const int c = c0 + n * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (o + r < Cout && c < Cin) atomicAdd(gw + ((long)(o + r) * Cin + c) * TAPS + t, acc[t][n][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ first layer (1 -> C1 channels)
+// forward: a1[pos][o] = lrelu(b[o] + sum_tap w[o][tap] x0[pos+tap]);  x0 [B][H][W] (one channel), a1 [B][H][W][C1]
+template <typename T>
+__global__ __launch_bounds__(256) void dfirst_fwd_kernel(const T* __restrict__ x0, const T* __restrict__ w, const T* __restrict__ bias,
+                                                         T* __restrict__ y, int H, int W, int C1, int kh, int kw, float slope) {
+  const int b = blockIdx.y, ph = kh / 2, pw = kw / 2;
+  const long npos = (long)H * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npos * C1; i += (long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % C1);
+    const long pos = i / C1;
+    const int h = (int)(pos / W), ww0 = (int)(pos % W);
+    float acc = bias ? ld<T>(bias + o) : 0.f;
+    for (int ih = 0; ih < kh; ++ih) {
+      const int hh = h + ih - ph;
+      if (hh < 0 || hh >= H) continue;
+      for (int iw = 0; iw < kw; ++iw) {
+        const int ww = ww0 + iw - pw;
+        if (ww < 0 || ww >= W) continue;
+        acc += ld<T>(w + (long)o * kh * kw + ih * kw + iw) * ld<T>(x0 + (long)b * npos + (long)hh * W + ww);
+      }
+    }
+    st<T>(y + ((long)b * npos + pos) * C1 + o, acc >= 0.f ? acc : acc * slope);
+  }
+}
+
+// data gradient: gx0[pos] = sum_{o,tap} w[o][tap] g1[pos - tap][o]   (g1 = d/d pre-activation, [B][H][W][C1]); one wave per position
+template <typename T>
+__global__ __launch_bounds__(256) void dfirst_dgrad_kernel(const T* __restrict__ g1, const T* __restrict__ w, T* __restrict__ gx0,
+                                                           int H, int W, int C1, int kh, int kw) {
+  const int lane = threadIdx.x & 63, b = blockIdx.y, ph = kh / 2, pw = kw / 2;
+  const long npos = (long)H * W;
+  const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= npos) return;
+  const int h = (int)(pos / W), ww0 = (int)(pos % W);
+  float acc = 0.f;
+  const int taps = kh * kw;
+  for (int e = lane; e < taps * C1; e += 64) {
+    const int o = e % C1, tap = e / C1, ih = tap / kw, iw = tap % kw;
+    const int hh = h - (ih - ph), ww = ww0 - (iw - pw);
+    if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+    acc += ld<T>(w + (long)o * taps + tap) * ld<T>(g1 + ((long)b * npos + (long)hh * W + ww) * C1 + o);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) st<T>(gx0 + (long)b * npos + pos, acc);
+}
+
+// weight gradient: gw[o][tap] += sum_pos g1[pos][o] x0[pos+tap]; gb[o] += sum_pos g1[pos][o]   (atomics across workgroups)
+template <typename T>
+__global__ __launch_bounds__(256) void dfirst_wgrad_kernel(const T* __restrict__ g1, const T* __restrict__ x0, float* __restrict__ gw,
+                                                           float* __restrict__ gb, int H, int W, int C1, int kh, int kw, int chunk) {
+  __shared__ float red[256 * 4];
+  const int b = blockIdx.y, ph = kh / 2, pw = kw / 2, taps = kh * kw;
+  const long npos = (long)H * W;
+  const int o = threadIdx.x % C1, part = threadIdx.x / C1, nparts = blockDim.x / C1;
+  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < npos ? p0 + chunk : npos;
+  for (int tap = -1; tap < taps; ++tap) {       // tap -1 = bias
+    const int ih = tap < 0 ? 0 : tap / kw, iw = tap < 0 ? 0 : tap % kw;
+    float acc = 0.f;
+    for (long pos = p0 + part; pos < p1; pos += nparts) {
+      const float gv = ld<T>(g1 + ((long)b * npos + pos) * C1 + o);
+      if (tap < 0) { acc += gv; continue; }
+      const int h = (int)(pos / W), ww0 = (int)(pos % W);
+      const int hh = h + ih - ph, ww = ww0 + iw - pw;
+      if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+      acc += gv * ld<T>(x0 + (long)b * npos + (long)hh * W + ww);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0) {
+      float s = 0.f;
+      for (int q = 0; q < nparts; ++q) s += red[q * C1 + o];
+      if (tap < 0) atomicAdd(gb + o, s); else atomicAdd(gw + (long)o * taps + tap, s);
+    }
+    __syncthreads();
+  }
+}
+
+// out[c] += sum_rows x[row][c]   (bias gradients of channels-last tensors)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_cl_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, int chunk) {
+  __shared__ float red[256];
+  const int c = threadIdx.x % C, part = threadIdx.x / C, nparts = blockDim.x / C;
+  const long r0 = (long)blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  float acc = 0.f;
+  for (long r = r0 + part; r < r1; r += nparts) acc += ld<T>(x + r * C + c);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (part == 0) {
+    float s = 0.f;
+    for (int q = 0; q < nparts; ++q) s += red[q * C + c];
+    atomicAdd(out + c, s);
+  }
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+extern "C" size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype) {
+  return (size_t)Cout * Cin * kh * kw * (dtype == MV_F32 ? 4 : 2);
+}
+
+extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip,
+                             int dtype, void* stream) {
+  MV_CHECK_ARG(w && packed && Cout % 16 == 0 && Cin % 32 == 0 && kh > 0 && kw > 0);
+  const int Mr = flip ? Cin : Cout, Kc = flip ? Cout : Cin;
+  MV_CHECK_ARG(Mr % 16 == 0 && Kc % 32 == 0);
+  const long total = (long)Cout * Cin * kh * kw;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  MV_DISPATCH(dtype, {
+    switch (param_dtype) {
+      case MV_F32: hipLaunchKernelGGL((dconv_pack_kernel<T, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
+      case MV_BF16: hipLaunchKernelGGL((dconv_pack_kernel<T, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
+      case MV_F16: hipLaunchKernelGGL((dconv_pack_kernel<T, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
+      default: return MV_ERR_DTYPE;
+    }
+  });
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+template <typename T, int MW, int NB>
+static int dconv_launch(const void* x, const void* wp, const void* bias, const void* actsave, void* y, DcP p, hipStream_t s) {
+  using M = Mma<T>;
+  const int prow = NB * 16 + p.kw - 1;
+  const size_t xb = (size_t)p.kh * prow * (p.Cin * M::ES + 16);
+  const size_t ob = (size_t)NB * 16 * (4 * MW * 16 * M::ES + 16);
+  const size_t lds = xb > ob ? xb : ob;
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = dconv_cl_kernel<T, MW, NB>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  dim3 grid(cdiv(p.W, NB * 16), cdiv(p.Cout / 16, 4 * MW), p.B * p.H);
+  if (grid.z > 65535) return MV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (const T*)wp, (const T*)bias, (const T*)actsave, (T*)y, p);
+  return MV_OK;
+}
+
+extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y,
+                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int act, float slope, int dtype,
+                               void* stream) {
+  MV_CHECK_ARG(x && packed && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 16 == 0 && (kh & 1) && (kw & 1));
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0 && Cout % 8 == 0);
+  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32};
+  int rc = MV_ERR_DTYPE;
+  MV_DISPATCH(dtype, {
+    if (Cout >= 128) {
+      rc = dconv_launch<T, 2, 8>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 2, 4>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+    } else {
+      rc = dconv_launch<T, 1, 8>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 1, 4>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+    }
+  });
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dhead_fwd(const void* x, const float* wt, float bias, void* y, int B, int H, int W, int C, int kh, int kw,
+                            int dtype, void* stream) {
+  MV_CHECK_ARG(x && wt && y && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0);
+  dim3 grid((unsigned)(((long)H * W + 3) / 4), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, wt, bias,
+                                        (T*)y, H, W, C, kh, kw));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
+                              int kw, float slope, int dtype, void* stream) {
+  MV_CHECK_ARG(g && wt && xsave && gx && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0);
+  const long n = (long)H * W * C;
+  dim3 grid((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_dgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, wt,
+                                        (const T*)xsave, (T*)gx, H, W, C, kh, kw, slope));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
+                              int dtype, void* stream) {
+  MV_CHECK_ARG(g && x && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C <= 1024 && C % 64 == 0);
+  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)kh * kw * C, (hipStream_t)stream);
+  hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream);
+  const int chunk = 256;
+  dim3 grid((unsigned)(((long)H * W + chunk - 1) / chunk), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_wgrad_kernel<T>, grid, dim3(C), 0, (hipStream_t)stream, (const T*)g, (const T*)x,
+                                        gw, gb, H, W, C, kh, kw, chunk));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+template <typename T, int NW, int TH, int TW_>
+static int dwgrad_launch(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+  const int WT = 128;
+  const int wsplit = cdiv(W, WT);
+  const int XC = NW * 16;
+  const size_t lds = (size_t)WT * (64 * 2 + 8) + (size_t)TH * (WT + TW_ - 1 + 8) * (XC * 2 + 8);
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = dconv_wgrad_kernel<T, NW, TH, TW_>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  const long nchunks = (long)B * H * wsplit;
+  if (nchunks > (1L << 30)) return MV_ERR_UNSUPPORTED;
+  const int tiles = cdiv(Cin, XC) * cdiv(Cout, 64);
+  // ~2048 workgroups in total: each loops over several position chunks, so the fp32 atomics at the end stay a few MB
+  int groups = 2048 / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
+  const int cpw = (int)((nchunks + groups - 1) / groups);
+  groups = (int)((nchunks + cpw - 1) / cpw);
+  dim3 grid(cdiv(Cin, XC), cdiv(Cout, 64), groups);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (const T*)g, gw, B, H, W, Cin, Cout, WT, wsplit,
+                     (int)nchunks, cpw);
+  return MV_OK;
+}
+
+extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, int kh,
+                                 int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(x && g && gw && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 64 == 0);
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
+  if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;   // 16-bit storage only (transposed LDS reads); callers fall back to the generic kernel
+  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, (hipStream_t)stream);
+  int rc = MV_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MV_BF16) {
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 2, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 2, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+  } else if (dtype == MV_F16) {
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 2, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 2, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+  }
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dfirst_fwd_cl(const void* x0, const void* w, const void* bias, void* y, int B, int H, int W, int C1, int kh,
+                                int kw, float slope, int dtype, void* stream) {
+  MV_CHECK_ARG(x0 && w && y && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0);
+  const long n = (long)H * W * C1;
+  dim3 grid((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x0, (const T*)w,
+                                        (const T*)bias, (T*)y, H, W, C1, kh, kw, slope));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, int B, int H, int W, int C1, int kh, int kw,
+                                  int dtype, void* stream) {
+  MV_CHECK_ARG(g1 && w && gx0 && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0);
+  dim3 grid((unsigned)(((long)H * W + 3) / 4), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_dgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g1, (const T*)w,
+                                        (T*)gx0, H, W, C1, kh, kw));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int B, int H, int W, int C1, int kh,
+                                  int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(g1 && x0 && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0 && 256 % C1 == 0);
+  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C1 * kh * kw, (hipStream_t)stream);
+  hipMemsetAsync(gb, 0, sizeof(float) * (size_t)C1, (hipStream_t)stream);
+  const int chunk = 1024;
+  dim3 grid((unsigned)(((long)H * W + chunk - 1) / chunk), B);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g1, (const T*)x0,
+                                        gw, gb, H, W, C1, kh, kw, chunk));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream) {
+  MV_CHECK_ARG(x && out && rows > 0 && C > 0 && C <= 256 && 256 % C == 0);
+  hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
+  const int chunk = 2048;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(colsum_cl_kernel<T>, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0,
+                                        (hipStream_t)stream, (const T*)x, out, rows, C, chunk));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -1,0 +1,155 @@
+"""Channels-last MFMA path of one discriminator stack (forward + backward), 16-bit storage.
+
+One ``torch.autograd.Function`` runs all five layers of a Discriminator2D / Discriminator1D
+(discriminators.py:56-66, :97-107): first layer (1 -> 32) and head (256 -> 1) as small dedicated kernels, the three
+wide layers on MFMA (``mv_dconv_cl_fwd``), their data gradients with the same kernel on flipped weights (LeakyReLU'
+fused in the epilogue) and their weight gradients with the transposed-LDS-read GEMM (``mv_dconv_wgrad_cl``).
+fp32 storage keeps using the generic kernels (functional.disc2d / disc1d).
+"""
+from __future__ import annotations
+
+from ctypes import c_void_p
+
+import torch
+from torch.autograd import Function
+
+from . import _native as N
+from . import ops
+
+_P = lambda t: None if t is None else c_void_p(t.data_ptr())
+
+
+class _PackCache:
+    def __init__(self):
+        self.d = {}
+
+    def get(self, w, dtype, flip):
+        key = (id(w), dtype, flip)
+        ver = (w._version, ops.param_epoch(), w.data_ptr())
+        hit = self.d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Cout, Cin, kh, kw = w.shape
+        buf = torch.empty(N.lib().mv_dconv_packed_bytes(Cout, Cin, kh, kw, ops._DT[dtype]), dtype=torch.uint8, device=w.device)
+        wd = w.detach().contiguous()
+        N.call("mv_dconv_pack", _P(wd), ops._DT[wd.dtype], _P(buf), Cout, Cin, kh, kw, int(flip), ops._DT[dtype], ops._stream())
+        self.d[key] = (ver, buf)
+        return buf
+
+    def head(self, w):
+        """[1,C,kh,kw] -> fp32 [kh*kw][C]."""
+        key = (id(w), "head")
+        ver = (w._version, ops.param_epoch(), w.data_ptr())
+        hit = self.d.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        C, taps = w.shape[1], w.shape[2] * w.shape[3]
+        wt = torch.empty(taps, C, device=w.device, dtype=torch.float32)
+        wd = w.detach().contiguous()
+        N.call("mv_conv_out_pack", _P(wd), ops._DT[wd.dtype], _P(wt), C, taps, ops._stream())
+        self.d[key] = (ver, wt)
+        return wt
+
+
+_packs = _PackCache()
+
+
+def _as4d(w):
+    return w if w.dim() == 4 else w.unsqueeze(2)        # Conv1d [O,C,k] -> [O,C,1,k]
+
+
+class _DiscStack(Function):
+    @staticmethod
+    def forward(ctx, x0, slope, *params):
+        """x0 [B,1,H,W] (MPD fold) or [B,1,W] (MSD, pooled); params = w1,b1,...,w5,b5."""
+        ws = [_as4d(p) for p in params[0::2]]
+        bs = list(params[1::2])
+        dt = x0.dtype
+        x0 = x0.contiguous()
+        B = x0.shape[0]
+        H, W = (x0.shape[2], x0.shape[3]) if x0.dim() == 4 else (1, x0.shape[2])
+        kh, kw = ws[0].shape[2], ws[0].shape[3]
+        st, dev = ops._stream, x0.device
+        cast = lambda t: ops._ParamCache.get(_cache, t, dt)
+        acts = []
+        C1 = ws[0].shape[0]
+        a = torch.empty(B, H, W, C1, device=dev, dtype=dt)
+        N.call("mv_dfirst_fwd_cl", _P(x0), _P(cast(ws[0])), _P(cast(bs[0])), _P(a), B, H, W, C1, kh, kw, float(slope), ops._dt(x0), st())
+        acts.append(a)
+        for li in (1, 2, 3):
+            Cout, Cin = ws[li].shape[0], ws[li].shape[1]
+            y = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
+            N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(ws[li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
+                   kh, kw, N.ACT_LRELU, float(slope), ops._dt(x0), st())
+            acts.append(y)
+        C4 = ws[4].shape[1]
+        out = torch.empty((B, 1, H, W) if x0.dim() == 4 else (B, 1, W), device=dev, dtype=dt)
+        bias5 = float(bs[4].detach().float().item()) if not hasattr(bs[4], "_mv_host") else bs[4]._mv_host
+        N.call("mv_dhead_fwd", _P(acts[-1]), _P(_packs.head(ws[4])), bias5, _P(out), B, H, W, C4, kh, kw, ops._dt(x0), st())
+        ctx.geom = (B, H, W, kh, kw, float(slope), x0.dim())
+        ctx.save_for_backward(x0, *acts, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        B, H, W, kh, kw, slope, xdim = ctx.geom
+        saved = ctx.saved_tensors
+        x0, acts, params = saved[0], list(saved[1:5]), list(saved[5:])
+        ws = [_as4d(p) for p in params[0::2]]
+        bs = list(params[1::2])
+        dt, dev, st = x0.dtype, x0.device, ops._stream
+        gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        need_w = any(need[2:])
+        grads = [None] * 10
+        f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        to = lambda g, p: (g.view(p.shape) if g.dtype == p.dtype else ops.cast(g.view(p.shape).contiguous(), p.dtype))
+        # ---- head
+        C4 = ws[4].shape[1]
+        if need_w:
+            gwt, gb5 = f32(kh * kw, C4), f32(1)
+            N.call("mv_dhead_wgrad", _P(gy), _P(acts[3]), _P(gwt), _P(gb5), B, H, W, C4, kh, kw, ops._dt(gy), st())
+            gw5 = f32(C4, kh * kw)                       # [taps][C] -> [C][taps] with our own transpose kernel
+            N.call("mv_ntc_to_nct", _P(gwt), _P(gw5), 1, C4, kh * kw, N.MV_F32, st())
+            grads[8], grads[9] = to(gw5, params[8]), to(gb5, params[9])
+        g = torch.empty(B, H, W, C4, device=dev, dtype=dt)
+        N.call("mv_dhead_dgrad", _P(gy), _P(_packs.head(ws[4])), _P(acts[3]), _P(g), B, H, W, C4, kh, kw, slope, ops._dt(gy), st())
+        # ---- wide layers 4, 3, 2 (indices 3, 2, 1)
+        for li in (3, 2, 1):
+            Cout, Cin = ws[li].shape[0], ws[li].shape[1]
+            if need_w:
+                gw = f32(Cout, Cin, kh, kw)
+                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), B, H, W, Cin, Cout, kh, kw, ops._dt(g), st())
+                gb = f32(Cout)
+                N.call("mv_colsum_cl", _P(g), _P(gb), B * H * W, Cout, ops._dt(g), st())
+                grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])
+            gprev = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
+            N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(ws[li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,
+                   kh, kw, N.ACT_NONE, slope, ops._dt(g), st())
+            g = gprev
+        # ---- first layer
+        C1 = ws[0].shape[0]
+        if need_w:
+            gw1, gb1 = f32(C1, kh * kw), f32(C1)
+            N.call("mv_dfirst_wgrad_cl", _P(g), _P(x0), _P(gw1), _P(gb1), B, H, W, C1, kh, kw, ops._dt(g), st())
+            grads[0], grads[1] = to(gw1, params[0]), to(gb1, params[1])
+        gx0 = None
+        if need[0]:
+            gx0 = torch.empty_like(x0)
+            N.call("mv_dfirst_dgrad_cl", _P(g), _P(ops._ParamCache.get(_cache, ws[0], dt)), _P(gx0), B, H, W, C1, kh, kw, ops._dt(g), st())
+        return (gx0, None, *grads)
+
+
+_cache = ops._ParamCache()
+
+
+def supported(x, blk) -> bool:
+    return x.dtype in (torch.bfloat16, torch.float16)
+
+
+def disc_stack(x0, blk, slope=0.1):
+    convs = [blk.conv_layers[i] for i in (0, 2, 4, 6, 8)]
+    params = []
+    for c in convs:
+        params += [c.weight, c.bias]
+    return _DiscStack.apply(x0, slope, *params)

@@ -406,6 +406,9 @@ def disc2d(x, blk):
         h = x.contiguous().view(B, C, blk.period, T // blk.period)   # exact multiple: the fold is a pure view
     else:
         h = _MpdFold.apply(x, blk.period)
+    from . import disc_fused
+    if disc_fused.supported(x, blk):      # 16-bit storage: channels-last MFMA stack (csrc/disc_fused.hip)
+        return disc_fused.disc_stack(h, blk)
     for li, conv in enumerate(_convs(blk.conv_layers)):
         h = conv2d(h, conv.weight, conv.bias, (1, 1), "lrelu" if li < 4 else None, 0.1)
     return h
@@ -414,6 +417,9 @@ def disc2d(x, blk):
 def disc1d(x, blk):
     """discriminators.py:109-117."""
     h = _AvgPool.apply(x, blk.scale) if blk.scale > 1 else x
+    from . import disc_fused
+    if disc_fused.supported(x, blk):
+        return disc_fused.disc_stack(h, blk)
     for li, conv in enumerate(_convs(blk.conv_layers)):
         h = conv1d(h, conv.weight, conv.bias, padding=7, act="lrelu" if li < 4 else None, slope=0.1)
     return h

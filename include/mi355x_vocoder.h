@@ -258,6 +258,41 @@ int mv_multi_gather(const void* descs_dev, int n_tensors, long max_len, float* f
 int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Channels-last MFMA discriminator convolutions.   replaces discriminators.py:57-65 (Conv2d 3x3 pad 1) and :98-106
+ * (Conv1d k15 pad 7), with their LeakyReLU(0.1), forward AND backward.   x [B][H][W][Cin], y [B][H][W][Cout], stride 1,
+ * odd kernels with "same" padding, Cin % 32 == 0, Cout % 16 == 0 (MSD: H = 1; MPD: H = period).
+ *   mv_dconv_pack(w [Cout,Cin,kh,kw], flip): MFMA A-fragment order; flip = 1 packs the data-gradient kernel
+ *     (taps flipped, channels transposed) - call mv_dconv_cl_fwd with Cin/Cout swapped on the output gradient.
+ *   mv_dconv_cl_fwd: y = act(conv(x) + bias).  act_save (optional, [B][H][W][Cout]): data-gradient mode - the result is
+ *     multiplied by LeakyReLU'(.) evaluated on that saved activation, i.e. it is d/d(pre-activation) of the previous layer.
+ *   mv_dhead_*: the Cout = 1 layer (weights as fp32 [kh*kw][C] from mv_conv_out_pack-style transposition).
+ *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3 and 1x15 kernels). */
+size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype);
+int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip, int dtype,
+                  void* stream);
+int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y, int B, int H,
+                    int W, int Cin, int Cout, int kh, int kw, int act, float slope, int dtype, void* stream);
+int mv_dhead_fwd(const void* x, const float* wt, float bias, void* y, int B, int H, int W, int C, int kh, int kw,
+                 int dtype, void* stream);
+int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
+                   int kw, float slope, int dtype, void* stream);
+int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
+                   int dtype, void* stream);
+int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                      int dtype, void* stream);
+
+/* First discriminator layer (1 -> C1 channels, LeakyReLU), channels-last output, and its gradients
+ * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */
+int mv_dfirst_fwd_cl(const void* x0, const void* w, const void* bias, void* y, int B, int H, int W, int C1, int kh,
+                     int kw, float slope, int dtype, void* stream);
+int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, int B, int H, int W, int C1, int kh, int kw, int dtype,
+                       void* stream);
+int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int B, int H, int W, int C1, int kh, int kw,
+                       int dtype, void* stream);
+/* out[c] = sum over rows of x[row][c] (bias gradient of a channels-last tensor); C divides 256. */
+int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -214,3 +214,57 @@ def test_train_step_runs_and_learns(H):
     assert all(np.isfinite(list(h.values())).all() for h in hist)
     assert (voc.generator.output_proj.weight.detach() - w0).abs().max() > 0
     assert torch.equal(next(voc.generator.unused_parameters()).detach(), u0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind,arg,T", [("2d", 3, 1000), ("2d", 2, 512), ("2d", 11, 700), ("1d", 2, 1000), ("1d", 1, 640)])
+@pytest.mark.parametrize("slope", [1.0, 0.1])
+def test_disc_fused_mfma_vs_fp32(H, dtype, kind, arg, T, slope):
+    """Channels-last MFMA discriminator stack (16-bit storage; csrc/disc_fused.hip): forward, input gradient and every
+    parameter gradient against an fp64 torch-CPU evaluation of the same stack.
+    slope = 1.0 makes the stack linear, so only rounding remains (tight bounds: this is the kernel-correctness check).
+    slope = 0.1 (the real LeakyReLU): 16-bit rounding flips the slope of pre-activations that sit within rounding of 0,
+    which costs ~sqrt(flipped fraction) in relative gradient error (measured 2-4 % fp16, 6-11 % bf16)."""
+    import torch.nn.functional as F
+    from hifigan_modified import disc_fused, functional as Fn
+    torch.manual_seed(0)
+    m = (H.Discriminator2D(arg) if kind == "2d" else H.Discriminator1D(arg))
+    torch.manual_seed(1)
+    x32 = torch.randn(3, 1, T).clamp(-1, 1)
+    # fp64 CPU reference
+    ps = {k: v.detach().double().requires_grad_(True) for k, v in m.named_parameters()}
+    xr = x32.double().requires_grad_(True)
+    if kind == "2d":
+        h = O.mpd_fold(xr, arg)
+        for li, idx in enumerate((0, 2, 4, 6, 8)):
+            h = F.conv2d(h, ps[f"conv_layers.{idx}.weight"], ps[f"conv_layers.{idx}.bias"], padding=1)
+            if li < 4:
+                h = torch.where(h >= 0, h, h * slope)
+    else:
+        h = xr[:, :, :T // arg * arg].reshape(3, 1, T // arg, arg).mean(3) if arg > 1 else xr
+        for li, idx in enumerate((0, 2, 4, 6, 8)):
+            h = F.conv1d(h, ps[f"conv_layers.{idx}.weight"], ps[f"conv_layers.{idx}.bias"], padding=7)
+            if li < 4:
+                h = torch.where(h >= 0, h, h * slope)
+    torch.manual_seed(2)
+    r = torch.randn_like(h)
+    (h * r).sum().backward()
+    # HIP path
+    m = m.cuda()
+    x = x32.cuda().to(dtype).requires_grad_(True)
+    if kind == "2d":
+        x0 = Fn._MpdFold.apply(x, arg) if T % arg else x.view(3, 1, arg, T // arg)
+    else:
+        x0 = Fn._AvgPool.apply(x, arg) if arg > 1 else x
+    y = disc_fused.disc_stack(x0, m, slope=slope)
+    assert y.shape == h.shape and y.dtype == dtype
+    (y.float() * r.float().cuda()).sum().backward()
+    errs = {"y": O.rel_l2(y.float().cpu(), h.detach().float()), "gx": O.rel_l2(x.grad.float().cpu(), xr.grad.float())}
+    for k, p in m.named_parameters():
+        errs[k] = O.rel_l2(p.grad.cpu(), ps[k].grad.float())
+    if slope == 1.0:
+        fwd_tol, g_tol = (2e-3, 4e-3) if dtype == torch.float16 else (1.5e-2, 3e-2)
+    else:
+        fwd_tol, g_tol = (3e-3, 6e-2) if dtype == torch.float16 else (2e-2, 1.6e-1)
+    assert errs["y"] < fwd_tol, errs
+    assert all(v < g_tol for k, v in errs.items() if k != "y"), {k: f"{v:.1e}" for k, v in errs.items()}
