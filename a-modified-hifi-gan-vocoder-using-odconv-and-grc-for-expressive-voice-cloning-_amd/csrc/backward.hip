@@ -24,8 +24,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gy, 
 // conv1d:  y[b,o,t] = sum_{c,j} w[o,c,j] x[b,c,t*stride - pad + j*dil]   (groups = 1)
 // gws[b?][o][c][j] = sum_t gy[b,o,t] x[b,c,t*stride-pad+j*dil]
 // One workgroup = 16(o) x 16(c) weight tile, all taps (ks <= 16), looping over time; per-sample results are
-//   nbanks == 1: accumulated over b into gw [Cout][Cin][ks] (one workgroup owns its tile: no atomics)
-//   nbanks  > 1: gw[k] += alpha[b,k] * tile ;  galpha[b,k] += <tile, w[k] tile>   (atomic per workgroup)
+//   nbanks == 1: gw [Cout][Cin][ks] += tile
+//   nbanks  > 1: gw[k] += alpha[b,k] * tile ;  galpha[b,k] += <tile, w[k] tile>   (both linear in the tile, so partial
+//                time chunks can be added independently; fp32 atomics)
 constexpr int WG_TT = 64;
 constexpr int WG_MAXKS = 16;
 
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
                                                            float* __restrict__ gw, float* __restrict__ galpha,
                                                            int B, int Cin, int Tin, int Cout, int Tout, int ks,
                                                            int stride, int pad, int dil, int nbanks,
-                                                           long x_bs, long x_cs, long g_bs, long g_cs) {
+                                                           long x_bs, long x_cs, long g_bs, long g_cs, int tsplit, int tchunk) {
+  // grid.z = B * tsplit: every workgroup reduces one (sample, time chunk) and adds its tile with fp32 atomics
   extern __shared__ __align__(16) float sm[];
   const int xw = (WG_TT - 1) * stride + (ks - 1) * dil + 1;
   float* xs = sm;                 // [16][xw]
@@ -44,58 +46,53 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
   const int tid = threadIdx.x, ol = tid >> 4, cl = tid & 15;
   const int o = blockIdx.y * 16 + ol, c = blockIdx.x * 16 + cl;
   const long wbank = (long)Cout * Cin * ks;
-  float tot[WG_MAXKS];
+  const int b = blockIdx.z / tsplit, tc = blockIdx.z % tsplit;
+  const int tbeg = tc * tchunk, tend = (tbeg + tchunk < Tout) ? tbeg + tchunk : Tout;
+  float acc[WG_MAXKS];
 #pragma unroll
-  for (int j = 0; j < WG_MAXKS; ++j) tot[j] = 0.f;
-
-  for (int b = 0; b < B; ++b) {
-    float acc[WG_MAXKS];
+  for (int j = 0; j < WG_MAXKS; ++j) acc[j] = 0.f;
+  for (int t0 = tbeg; t0 < tend; t0 += WG_TT) {
+    const int tin0 = t0 * stride - pad;
+    for (int i = tid; i < 16 * xw; i += 256) {
+      const int cc = i / xw, xi = i % xw, ci = blockIdx.x * 16 + cc, tin = tin0 + xi;
+      xs[i] = (ci < Cin && tin >= 0 && tin < Tin) ? ld<T>(x + (long)b * x_bs + (long)ci * x_cs + tin) : 0.f;
+    }
+    for (int i = tid; i < 16 * WG_TT; i += 256) {
+      const int oo = i / WG_TT, ti = i % WG_TT, co = blockIdx.y * 16 + oo, t = t0 + ti;
+      gs[i] = (co < Cout && t < tend) ? ld<T>(gy + (long)b * g_bs + (long)co * g_cs + t) : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < WG_TT; ++t) {
+      const float g = gs[ol * WG_TT + t];
+      const float* xr = xs + cl * xw + t * stride;
 #pragma unroll
-    for (int j = 0; j < WG_MAXKS; ++j) acc[j] = 0.f;
-    for (int t0 = 0; t0 < Tout; t0 += WG_TT) {
-      const int tin0 = t0 * stride - pad;
-      for (int i = tid; i < 16 * xw; i += 256) {
-        const int cc = i / xw, xi = i % xw, ci = blockIdx.x * 16 + cc, tin = tin0 + xi;
-        xs[i] = (ci < Cin && tin >= 0 && tin < Tin) ? ld<T>(x + (long)b * x_bs + (long)ci * x_cs + tin) : 0.f;
-      }
-      for (int i = tid; i < 16 * WG_TT; i += 256) {
-        const int oo = i / WG_TT, ti = i % WG_TT, co = blockIdx.y * 16 + oo, t = t0 + ti;
-        gs[i] = (co < Cout && t < Tout) ? ld<T>(gy + (long)b * g_bs + (long)co * g_cs + t) : 0.f;
-      }
-      __syncthreads();
-      for (int t = 0; t < WG_TT; ++t) {
-        const float g = gs[ol * WG_TT + t];
-        const float* xr = xs + cl * xw + t * stride;
+      for (int j = 0; j < WG_MAXKS; ++j)
+        if (j < ks) acc[j] += g * xr[j * dil];
+    }
+    __syncthreads();
+  }
+  const bool ok = o < Cout && c < Cin;
+  if (nbanks == 1) {
+    if (ok) {
+      float* gwk = gw + ((long)o * Cin + c) * ks;
+#pragma unroll
+      for (int j = 0; j < WG_MAXKS; ++j)
+        if (j < ks) atomicAdd(gwk + j, acc[j]);
+    }
+  } else {
+    for (int k = 0; k < nbanks; ++k) {
+      const float a = alpha[b * nbanks + k];
+      float dot = 0.f;
+      if (ok) {
+        float* gwk = gw + k * wbank + ((long)o * Cin + c) * ks;
+        const T* wk = w + k * wbank + ((long)o * Cin + c) * ks;
 #pragma unroll
         for (int j = 0; j < WG_MAXKS; ++j)
-          if (j < ks) acc[j] += g * xr[j * dil];
+          if (j < ks) { atomicAdd(gwk + j, a * acc[j]); dot += acc[j] * ld<T>(wk + j); }
       }
-      __syncthreads();
+      dot = block_sum(dot, red);
+      if (tid == 0) atomicAdd(galpha + b * nbanks + k, dot);
     }
-    if (nbanks == 1) {
-#pragma unroll
-      for (int j = 0; j < WG_MAXKS; ++j) tot[j] += acc[j];
-    } else {
-      const bool ok = o < Cout && c < Cin;
-      for (int k = 0; k < nbanks; ++k) {
-        const float a = alpha[b * nbanks + k];
-        float dot = 0.f;
-        if (ok) {
-          float* gwk = gw + k * wbank + ((long)o * Cin + c) * ks;
-          const T* wk = w + k * wbank + ((long)o * Cin + c) * ks;
-#pragma unroll
-          for (int j = 0; j < WG_MAXKS; ++j)
-            if (j < ks) { gwk[j] += a * acc[j]; dot += acc[j] * ld<T>(wk + j); }
-        }
-        dot = block_sum(dot, red);
-        if (tid == 0) atomicAdd(galpha + b * nbanks + k, dot);
-      }
-    }
-  }
-  if (nbanks == 1 && o < Cout && c < Cin) {
-#pragma unroll
-    for (int j = 0; j < WG_MAXKS; ++j)
-      if (j < ks) gw[((long)o * Cin + c) * ks + j] = tot[j];
   }
 }
 
@@ -389,13 +386,20 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
   const int xw = (WG_TT - 1) * stride + (ks - 1) * dil + 1;
   const size_t lds = sizeof(float) * (16 * xw + 16 * WG_TT + 32);
   if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
-  dim3 grid(cdiv(Cin, 16), cdiv(Cout, 16));
-  if (nbanks > 1) {  // accumulated across samples inside the kernel: start from zero
-    hipMemsetAsync(gw, 0, sizeof(float) * (size_t)nbanks * Cout * Cin * ks, (hipStream_t)stream);
-  }
+  // split time so that ~2048 workgroups exist; every workgroup adds its partial tile atomically
+  const int tiles = cdiv(Cin, 16) * cdiv(Cout, 16);
+  int tsplit = cdiv(2048, tiles * B);
+  const int max_split = cdiv(Tout, WG_TT);
+  if (tsplit > max_split) tsplit = max_split;
+  if (tsplit < 1) tsplit = 1;
+  const int tchunk = cdiv(cdiv(Tout, tsplit), WG_TT) * WG_TT;
+  tsplit = cdiv(Tout, tchunk);
+  if ((long)B * tsplit > 65535) return MV_ERR_UNSUPPORTED;
+  dim3 grid(cdiv(Cin, 16), cdiv(Cout, 16), B * tsplit);
+  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)nbanks * Cout * Cin * ks, (hipStream_t)stream);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(conv1d_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x,
                                         (const T*)gy, (const T*)w, alpha, gw, galpha, B, Cin, Tin, Cout, Tout, ks,
-                                        stride, pad, dil, nbanks, x_bs, x_cs, g_bs, g_cs));
+                                        stride, pad, dil, nbanks, x_bs, x_cs, g_bs, g_cs, tsplit, tchunk));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -168,7 +168,7 @@ __device__ __forceinline__ int reflect_idx(int i, int Tn) {
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wave, const float* __restrict__ fb,
-                                                       const T* __restrict__ target, float* __restrict__ mel_out,
+                                                       const float* __restrict__ target, float* __restrict__ mel_out,
                                                        float* __restrict__ loss_acc, float* __restrict__ gwave,
                                                        int Tn, int n_fft, int hop, int n_mels, int n_frames, float clampv,
                                                        float weight, long n_total, int kind) {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wav
     if (mel_out) mel_out[((long)b * n_mels + m) * n_frames + f] = lm;
     float g = 0.f;
     if (target) {
-      const float d = lm - ld<T>(target + ((long)b * n_mels + m) * n_frames + f);
+      const float d = lm - target[((long)b * n_mels + m) * n_frames + f];
       lsum += kind == 0 ? fabsf(d) : d * d;
       g = (kind == 0 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * d) * (weight / (float)n_total);
     }
@@ -317,7 +317,7 @@ extern "C" int mv_multi_gather(const void* descs_dev, int n_tensors, long max_le
   return MV_OK;
 }
 
-extern "C" int mv_mel_loss(const void* wave, const float* fb, const void* target, float* mel_out, float* loss_acc,
+extern "C" int mv_mel_loss(const void* wave, const float* fb, const float* target, float* mel_out, float* loss_acc,
                            float* gwave, int B, int T_, int n_fft, int hop, int n_mels, float clampv, float weight,
                            int kind, int backward, int dtype, void* stream) {
   MV_CHECK_ARG(wave && fb && B > 0 && T_ > 0 && n_fft > 0 && hop > 0 && n_mels > 0 && T_ % hop == 0 && n_fft >= hop);
@@ -333,12 +333,12 @@ extern "C" int mv_mel_loss(const void* wave, const float* fb, const void* target
     if (backward) {
       auto kern = mel_loss_kernel<T, true>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, (const T*)target, mel_out,
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, target, mel_out,
                          loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
     } else {
       auto kern = mel_loss_kernel<T, false>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, (const T*)target, mel_out,
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, target, mel_out,
                          loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
     }
   });

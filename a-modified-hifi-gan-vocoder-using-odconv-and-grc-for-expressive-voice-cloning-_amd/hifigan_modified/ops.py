@@ -433,6 +433,8 @@ def mel_loss(wave, fb, target=None, n_fft=1024, hop=256, clampv=1e-5, weight=1.0
     acc = torch.zeros(1, device=wave.device, dtype=torch.float32)
     mel = _f32(B, n_mels, T // hop, device=wave.device) if want_mel else None
     gwave = torch.zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None
-    N.call("mv_mel_loss", _p(wave), _p(fb), _p(_c(target)), _p(mel), _p(acc), _p(gwave), B, T, n_fft, hop, n_mels,
+    if target is not None:
+        target = cast(_c(target), torch.float32)
+    N.call("mv_mel_loss", _p(wave), _p(fb), _p(target), _p(mel), _p(acc), _p(gwave), B, T, n_fft, hop, n_mels,
            float(clampv), float(weight), int(kind), int(backward), _dt(wave), _stream())
     return acc, mel, gwave
