@@ -224,30 +224,51 @@ __global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ 
   }
 }
 
-// weight gradient of the head: gw[tap][c] = sum_{b,pos} g[pos] x[pos+tap][c]; gb = sum g.   (atomic across workgroups)
+// weight gradient of the head: gw[tap][c] = sum_{b,pos} g[pos] x[pos+tap][c]; gb = sum g.
+// One workgroup = one output row (b,h) x a chunk of columns; thread = channel.  Every x element is read ONCE (all taps that
+// use it are accumulated from the LDS-staged g window), results leave with fp32 atomics.
+constexpr int DH_MAXTAPS = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void dhead_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                           float* __restrict__ gw, float* __restrict__ gb, int H, int W,
                                                           int C, int kh, int kw, int chunk) {
-  const int b = blockIdx.y, c = threadIdx.x;            // blockDim.x == C (256)
+  extern __shared__ float gs[];                     // [kh][chunk + kw - 1] g rows h-ph..h+ph (as seen from the x row)
+  const int b = blockIdx.z, hx = blockIdx.y;        // hx: row of x being read
   const int ph = kh / 2, pw = kw / 2;
-  const long npos = (long)H * W;
-  const long p0 = (long)blockIdx.x * chunk, p1 = p0 + chunk < npos ? p0 + chunk : npos;
-  float gbs = 0.f;
-  for (int ih = 0; ih < kh; ++ih)
-    for (int iw = 0; iw < kw; ++iw) {
-      float acc = 0.f;
-      for (long pos = p0; pos < p1; ++pos) {
-        const int h = (int)(pos / W), w = (int)(pos % W);
-        const int hh = h + ih - ph, ww = w + iw - pw;
-        const float gv = ld<T>(g + (long)b * npos + pos);
-        if (ih == 0 && iw == 0 && c == 0) gbs += gv;
-        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-        acc += gv * ld<T>(x + (((long)b * H + hh) * W + ww) * C + c);
+  const int w0 = blockIdx.x * chunk;
+  const int gwid = chunk + kw - 1;
+  // x[hx][wx] contributes to gw[ih][iw] with g[hx - (ih-ph)][wx - (iw-pw)]
+  for (int i = threadIdx.x; i < kh * gwid; i += blockDim.x) {
+    const int ih = i / gwid, j = i % gwid;
+    const int hg = hx - (ih - ph), wg = w0 - pw + j;   // j indexes wg from w0-pw .. w0+chunk+pw-1
+    gs[i] = (hg >= 0 && hg < H && wg >= 0 && wg < W) ? ld<T>(g + ((long)b * H + hg) * W + wg) : 0.f;
+  }
+  __syncthreads();
+  float acc[DH_MAXTAPS];
+#pragma unroll
+  for (int t = 0; t < DH_MAXTAPS; ++t) acc[t] = 0.f;
+  const int wend = (w0 + chunk < W) ? w0 + chunk : W;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int ih = 0; ih < kh; ++ih) {
+#pragma unroll
+      for (int t = 0; t < DH_MAXTAPS; ++t) acc[t] = 0.f;
+      for (int wx = w0; wx < wend; ++wx) {
+        const float xv = ld<T>(x + (((long)b * H + hx) * W + wx) * C + c);
+        const float* gr = gs + ih * gwid + (wx - w0) + 2 * pw;   // g at wx - (iw - pw) = index (wx - w0 + pw) + (pw - iw)
+#pragma unroll
+        for (int iw = 0; iw < DH_MAXTAPS; ++iw)
+          if (iw < kw) acc[iw] += gr[-iw] * xv;
       }
-      atomicAdd(gw + (ih * kw + iw) * C + c, acc);
+#pragma unroll
+      for (int iw = 0; iw < DH_MAXTAPS; ++iw)
+        if (iw < kw) atomicAdd(gw + (ih * kw + iw) * C + c, acc[iw]);
     }
-  if (c == 0) atomicAdd(gb, gbs);
+  }
+  if (gb && hx < H && threadIdx.x == 0) {            // bias: sum of g over this (row, chunk) - rows of g == rows of x
+    float s = 0.f;
+    for (int wx = w0; wx < wend; ++wx) s += gs[ph * gwid + (wx - w0) + pw];
+    atomicAdd(gb, s);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA weight gradient
@@ -427,20 +448,33 @@ __global__ __launch_bounds__(256) void dfirst_wgrad_kernel(const T* __restrict__
   }
 }
 
-// out[c] += sum_rows x[row][c]   (bias gradients of channels-last tensors)
+// out[c] += sum_rows x[row][c]   (bias gradients of channels-last tensors); one thread = 16 bytes of a row
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_cl_kernel(const T* __restrict__ x, float* __restrict__ out, long rows, int C, int chunk) {
-  __shared__ float red[256];
-  const int c = threadIdx.x % C, part = threadIdx.x / C, nparts = blockDim.x / C;
+  constexpr int EPC = 16 / sizeof(T);
+  __shared__ float red[256 * EPC];
+  const int tpr = C / EPC;                           // threads per row
+  const int cg = threadIdx.x % tpr, part = threadIdx.x / tpr, nparts = blockDim.x / tpr;
   const long r0 = (long)blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
-  float acc = 0.f;
-  for (long r = r0 + part; r < r1; r += nparts) acc += ld<T>(x + r * C + c);
-  red[threadIdx.x] = acc;
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  for (long r = r0 + part; r < r1; r += nparts) {
+    T tmp[EPC];
+    *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(x + r * C + cg * EPC);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] += ld<T>(tmp + e);
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) red[threadIdx.x * EPC + e] = acc[e];
   __syncthreads();
   if (part == 0) {
-    float s = 0.f;
-    for (int q = 0; q < nparts; ++q) s += red[q * C + c];
-    atomicAdd(out + c, s);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float sum = 0.f;
+      for (int q = 0; q < nparts; ++q) sum += red[(q * tpr + cg) * EPC + e];
+      atomicAdd(out + cg * EPC + e, sum);
+    }
   }
 }
 
@@ -535,10 +569,12 @@ extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb
   MV_CHECK_ARG(g && x && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C <= 1024 && C % 64 == 0);
   hipMemsetAsync(gw, 0, sizeof(float) * (size_t)kh * kw * C, (hipStream_t)stream);
   hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream);
+  MV_CHECK_ARG(kw <= DH_MAXTAPS && H <= 65535);
   const int chunk = 256;
-  dim3 grid((unsigned)(((long)H * W + chunk - 1) / chunk), B);
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_wgrad_kernel<T>, grid, dim3(C), 0, (hipStream_t)stream, (const T*)g, (const T*)x,
-                                        gw, gb, H, W, C, kh, kw, chunk));
+  dim3 grid(cdiv(W, chunk), H, B);
+  const size_t lds = sizeof(float) * (size_t)kh * (chunk + kw - 1);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)g,
+                                        (const T*)x, gw, gb, H, W, C, kh, kw, chunk));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
@@ -621,8 +657,9 @@ extern "C" int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, flo
 }
 
 extern "C" int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream) {
-  MV_CHECK_ARG(x && out && rows > 0 && C > 0 && C <= 256 && 256 % C == 0);
+  MV_CHECK_ARG(x && out && rows > 0 && C >= 8 && C <= 2048 && C % 8 == 0 && (256 % (C / 8)) == 0 && ((uintptr_t)x & 15) == 0);
   hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, (hipStream_t)stream);
+  if (dtype == MV_F32 && (256 % (C / 4)) != 0) return MV_ERR_UNSUPPORTED;
   const int chunk = 2048;
   MV_DISPATCH(dtype, hipLaunchKernelGGL(colsum_cl_kernel<T>, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)x, out, rows, C, chunk));
