@@ -272,103 +272,114 @@ __global__ __launch_bounds__(256) void dhead_wgrad_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA weight gradient
-// gw[o][tap][c] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
-// workgroup: 4 waves; wave w owns M-tile (o) = blockIdx.y*4 + w and NW 16-channel N-tiles starting at blockIdx.x*NW*16;
-// positions: row (b,h) = blockIdx.z / wsplit, column chunk (blockIdx.z % wsplit) * WT .. +WT
-template <typename T, int NW, int TAPS_H, int TAPS_W>
+// gw[o][c][tap] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
+// workgroup = 4 waves arranged 2 (o) x 2 (c): wave (wm, wn) owns output channels o0 + 32*wm .. +31 (2 M-tiles) and input
+// channels c0 + 32*wn .. +31 (2 N-tiles) for TG consecutive taps starting at blockIdx.x % tap_groups * TG:
+// 4 transposed reads feed 4 MFMAs per tap, the accumulators of all TG taps stay in registers across the position chunks
+// the workgroup loops over, and only the final tiles are added to HBM with fp32 atomics.
+template <typename T, int TG, int TAPS_H, int TAPS_W>
 __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                           float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
-                                                          int WT, int wsplit, int nchunks, int chunks_per_wg) {
+                                                          int WT, int wsplit, int nchunks, int chunks_per_wg, int tap_groups) {
   static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
   using M = Mma<T>;
   typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
   constexpr int TAPS = TAPS_H * TAPS_W;
   constexpr int PH = TAPS_H / 2, PW = TAPS_W / 2;
   extern __shared__ __align__(16) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;   // transposed-read lane roles (guide T10)
-  const int o0 = (blockIdx.y * 4) * 16;            // first output channel of the workgroup (64 channels)
-  const int c0 = blockIdx.x * NW * 16;             // first input channel of the workgroup (NW*16 channels)
-  constexpr int GC = 64;                           // g tile channels
-  const int XC = NW * 16;
-  const int GRS = GC * 2 + 8, XRS = XC * 2 + 8;    // row strides (bytes), multiples of 8
+  const int ctile = blockIdx.x / tap_groups, tgi = blockIdx.x % tap_groups;
+  const int tap0 = tgi * TG;
+  const int o0 = blockIdx.y * 64, c0 = ctile * 64;
+  constexpr int GC = 64, XC = 64;
+  constexpr int GRS = GC * 2 + 8, XRS = XC * 2 + 8;    // row strides (bytes), multiples of 8
   const int xcols = WT + TAPS_W - 1;
   char* gl = lds;                                   // [WT][GC]
   char* xl = lds + (size_t)WT * GRS;                // [TAPS_H][xcols][XC]
 
-  f32x4 acc[TAPS][NW];
+  f32x4 acc[TG][2][2];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TG; ++t)
 #pragma unroll
-    for (int n = 0; n < NW; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const char* ga = gl + (size_t)(8 * grp + q) * GRS + (wid * 16 + 4 * pp) * 2;
-  const char* xa = xl + (size_t)(8 * grp + q) * XRS + (4 * pp) * 2;
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* ga = gl + (size_t)(8 * grp + q) * GRS + (wm * 32 + 4 * pp) * 2;
+  const char* xa = xl + (size_t)(8 * grp + q) * XRS + (wn * 32 + 4 * pp) * 2;
+  auto trload = [&](const char* p0, const char* p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    typename M::V r;
+    r.v = __builtin_bit_cast(decltype(r.v), both);
+    return r;
+  };
 
   for (int ci = 0; ci < chunks_per_wg; ++ci) {
-  const int chunk = blockIdx.z * chunks_per_wg + ci;
-  if (chunk >= nchunks) break;                       // uniform across the workgroup
-  const int bh = chunk / wsplit, wc = chunk % wsplit;
-  const int b = bh / H, h = bh % H;
-  const int w0 = wc * WT;
-  if (ci) __syncthreads();                           // previous chunk's reads are done before restaging
-  // stage g tile (positions w0..w0+WT-1, channels o0..o0+63) and x planes (rows h-PH.., cols w0-PW.., channels c0..)
-  for (int i = tid; i < WT * (GC / 4); i += 256) {
-    const int r = i / (GC / 4), ch = i % (GC / 4);
-    const int ww = w0 + r;
-    u32x2 v = {0u, 0u};
-    if (ww < W && o0 + ch * 4 < Cout)
-      v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(g + (((long)b * H + h) * W + ww) * Cout + o0) + ch * 8);
-    *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 8) = v;
-  }
-  for (int i = tid; i < TAPS_H * xcols * (XC / 4); i += 256) {
-    const int ch = i % (XC / 4), r = (i / (XC / 4)) % xcols, pl = i / ((XC / 4) * xcols);
-    const int hh = h - PH + pl, ww = w0 - PW + r;
-    u32x2 v = {0u, 0u};
-    if (hh >= 0 && hh < H && ww >= 0 && ww < W)
-      v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const char*>(x + (((long)b * H + hh) * W + ww) * Cin + c0) + ch * 8);
-    *reinterpret_cast<u32x2*>(xl + ((size_t)pl * xcols + r) * XRS + ch * 8) = v;
-  }
-  __syncthreads();
-
-  // A[row o][k = pos]: transposed read of the g tile: block rows = positions (k), columns = 16 channels of this wave's M-tile
-  // lane (4q+pp) of group grp supplies the address of block row q, columns 4pp..4pp+3; MFMA k index of the lane = 8*grp + j
-  for (int k0 = 0; k0 < WT; k0 += 32) {
-    typename M::V a;
-    {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ga + (size_t)k0 * GRS));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ga + (size_t)(k0 + 4) * GRS));
-      typedef __attribute__((ext_vector_type(8))) short s16x8;
-      const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      a.v = __builtin_bit_cast(decltype(a.v), both);
+    const int chunk = blockIdx.z * chunks_per_wg + ci;
+    if (chunk >= nchunks) break;                       // uniform across the workgroup
+    const int bh = chunk / wsplit, wc = chunk % wsplit;
+    const int b = bh / H, h = bh % H;
+    const int w0 = wc * WT;
+    if (ci) __syncthreads();                           // previous chunk's reads are done before restaging
+    // stage g tile (positions w0.., channels o0..o0+63) and the x planes (rows h-PH.., cols w0-PW.., channels c0..c0+63)
+    for (int i = tid; i < WT * (GC / 8); i += 256) {
+      const int r = i / (GC / 8), ch = i % (GC / 8);
+      const int ww = w0 + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ww < W) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g + (((long)b * H + h) * W + ww) * Cout + o0) + ch * 16);
+      *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 16) = u32x2{v[0], v[1]};
+      *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 16 + 8) = u32x2{v[2], v[3]};
     }
+    for (int i = tid; i < TAPS_H * xcols * (XC / 8); i += 256) {
+      const int ch = i % (XC / 8), r = (i / (XC / 8)) % xcols, pl = i / ((XC / 8) * xcols);
+      const int hh = h - PH + pl, ww = w0 - PW + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + (((long)b * H + hh) * W + ww) * Cin + c0) + ch * 16);
+      char* dst = xl + ((size_t)pl * xcols + r) * XRS + ch * 16;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{v[0], v[1]};
+      *reinterpret_cast<u32x2*>(dst + 8) = u32x2{v[2], v[3]};
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < WT; k0 += 32) {
+      typename M::V a[2];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int ih = t / TAPS_W, iw = t % TAPS_W;
+      for (int m = 0; m < 2; ++m) a[m] = trload(ga + (size_t)k0 * GRS + m * 32, ga + (size_t)(k0 + 4) * GRS + m * 32);
 #pragma unroll
-      for (int n = 0; n < NW; ++n) {
-        const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS + n * 32;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)pb);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(pb + 4 * XRS));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        typename M::V bfr;
-        bfr.v = __builtin_bit_cast(decltype(bfr.v), both);
-        acc[t][n] = M::mma(a, bfr, acc[t][n]);
+      for (int t = 0; t < TG; ++t) {
+        const int tap = tap0 + t;
+        if (tap < TAPS) {
+          const int ih = tap / TAPS_W, iw = tap % TAPS_W;
+          const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS;
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const typename M::V bfr = trload(pb + n * 32, pb + 4 * XRS + n * 32);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[t][m][n] = M::mma(a[m], bfr, acc[t][m][n]);
+          }
+        }
       }
     }
   }
-  }  // chunk loop
   // D[row = o (4*grp + r)][col = c (li)] -> gw[o][c][tap]  (reference layout [Cout][Cin][kh][kw])
-  const int o = o0 + wid * 16 + 4 * grp;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TG; ++t) {
+    const int tap = tap0 + t;
+    if (tap >= TAPS) continue;
 #pragma unroll
-    for (int n = 0; n < NW; ++n) {
-      const int c = c0 + n * 16 + li;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (o + r < Cout && c < Cin) atomicAdd(gw + ((long)(o + r) * Cin + c) * TAPS + t, acc[t][n][r]);
-    }
+      for (int n = 0; n < 2; ++n) {
+        const int o = o0 + wm * 32 + m * 16 + 4 * grp, c = c0 + wn * 32 + n * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (o + r < Cout && c < Cin) atomicAdd(gw + ((long)(o + r) * Cin + c) * TAPS + tap, acc[t][m][n][r]);
+      }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ first layer (1 -> C1 channels)
@@ -579,26 +590,26 @@ extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb
   return MV_OK;
 }
 
-template <typename T, int NW, int TH, int TW_>
+template <typename T, int TG, int TH, int TW_>
 static int dwgrad_launch(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
   const int WT = 128;
   const int wsplit = cdiv(W, WT);
-  const int XC = NW * 16;
-  const size_t lds = (size_t)WT * (64 * 2 + 8) + (size_t)TH * (WT + TW_ - 1 + 8) * (XC * 2 + 8);
+  const size_t lds = (size_t)WT * (64 * 2 + 8) + (size_t)TH * (WT + TW_ - 1) * (64 * 2 + 8);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = dconv_wgrad_kernel<T, NW, TH, TW_>;
+  auto kern = dconv_wgrad_kernel<T, TG, TH, TW_>;
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   const long nchunks = (long)B * H * wsplit;
   if (nchunks > (1L << 30)) return MV_ERR_UNSUPPORTED;
-  const int tiles = cdiv(Cin, XC) * cdiv(Cout, 64);
+  const int tap_groups = cdiv(TH * TW_, TG);
+  const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64) * tap_groups;
   // ~2048 workgroups in total: each loops over several position chunks, so the fp32 atomics at the end stay a few MB
   int groups = 2048 / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
   const int cpw = (int)((nchunks + groups - 1) / groups);
   groups = (int)((nchunks + cpw - 1) / cpw);
-  dim3 grid(cdiv(Cin, XC), cdiv(Cout, 64), groups);
+  dim3 grid(cdiv(Cin, 64) * tap_groups, cdiv(Cout, 64), groups);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (const T*)g, gw, B, H, W, Cin, Cout, WT, wsplit,
-                     (int)nchunks, cpw);
+                     (int)nchunks, cpw, tap_groups);
   return MV_OK;
 }
 
@@ -611,11 +622,11 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, int B,
   int rc = MV_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MV_BF16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 2, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 2, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 3, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 5, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
   } else if (dtype == MV_F16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 2, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 2, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 3, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 5, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
   }
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();

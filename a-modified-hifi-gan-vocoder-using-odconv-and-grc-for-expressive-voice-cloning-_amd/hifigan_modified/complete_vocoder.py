@@ -154,7 +154,7 @@ class VocoderTrainer:
     @staticmethod
     def to_floats(losses):
         """Host read-back of a loss dict (kept out of train_step so a step does not force a device sync)."""
-        return {k: float(v) for k, v in losses.items()}
+        return {k: float(v.detach()) for k, v in losses.items()}
 
     def save_checkpoint(self, path: str):
         torch.save({"vocoder_state_dict": self.vocoder.state_dict(),

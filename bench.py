@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
+    ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -154,6 +157,70 @@ def main():
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
                 "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic"}
 
+    # ---------------------------------------------------------------- training metric (BASELINE configs[2]/[3])
+    # full two-optimizer step (complete_vocoder.py:199-233): G forward -> D step -> G step, + mel/STFT loss, + AdamW;
+    # data parallel: 32 clips per GPU, one all-reduce of the flat gradient buffer per optimizer step (RCCL)
+    train = None
+    if args.train_steps > 0:
+        from hifigan_modified.parallel import GradSynchronizer, broadcast_parameters
+        tdtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.train_dtype]
+        torch.manual_seed(0)
+        voc = H.ModifiedHiFiGANVocoder().to(dev)
+        if world > 1:
+            broadcast_parameters(voc)
+        trainer = H.VocoderTrainer(voc, device=dev, grad_sync=GradSynchronizer() if world > 1 else None)
+        torch.manual_seed(100 + rank)
+        tmel = torch.randn(B, 80, Tm, device=dev).to(tdtype)
+        treal = torch.randn(B, 1, Tm * 256, device=dev).clamp(-1, 1).to(tdtype)
+        tspk, temo = torch.randn(B, 192, device=dev).to(tdtype), torch.randn(B, 384, device=dev).to(tdtype)
+        torch.manual_seed(2 + rank)      # dropout stream of this rank
+        for _ in range(args.train_warmup):
+            losses = trainer.train_step(tmel, treal, tspk, temo)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            losses = trainer.train_step(tmel, treal, tspk, temo)
+        sync_all()
+        tel = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([tel], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tel = float(t.item())
+        lf = trainer.to_floats(losses)
+        train = {"metric": "train audio-samples/s (G fwd + D step + G step + mel/STFT loss + AdamW)",
+                 "value": round(B * Tm * 256 * world * args.train_steps / tel, 1), "unit": "samples/s",
+                 "ms_per_step": round(tel / args.train_steps * 1e3, 2), "steps": args.train_steps, "dtype": args.train_dtype,
+                 "global_batch": B * world, "losses_finite": all(x == x and abs(x) != float("inf") for x in lf.values()),
+                 "parallelism": "dp%d, flat-bucket all-reduce over RCCL" % world if world > 1 else "single GPU"}
+        if rank == 0 and tdtype != torch.float32:
+            # MFMA roofline of the dominant discriminator conv (128 -> 256, 3x3, period-2 fold of the real+fake batch)
+            import ctypes
+            from hifigan_modified import ops as _ops, _native as _N, disc_fused as _df
+            conv = voc.discriminators.mpd.discriminators[0].conv_layers[6]
+            Bd, Hd, Wd = 2 * B, 2, Tm * 256 // 2
+            xin = torch.randn(Bd, Hd, Wd, 128, device=dev).to(tdtype)
+            yout = torch.empty(Bd, Hd, Wd, 256, device=dev, dtype=tdtype)
+            pk = _df._packs.get(conv.weight, tdtype, 0)
+            bias = conv.bias.detach().to(tdtype)
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            def run():
+                _N.call("mv_dconv_cl_fwd", P(xin), P(pk), P(bias), None, P(yout), Bd, Hd, Wd, 128, 256, 3, 3, _N.ACT_LRELU, 0.1,
+                        _ops._dt(xin), _ops._stream())
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            flops = 2.0 * Bd * Hd * Wd * 256 * 128 * 9
+            ach = flops / (ms * 1e-3) / 1e12
+            train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_kernel (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM)",
+                                 "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                                 "traffic": None, "flops_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
     if rank == 0:
         frames = B * Tm * world * args.steps
         out = {
@@ -167,6 +234,7 @@ def main():
             "samples_per_s": round(frames * 256 / elapsed, 1),
             "parity_rel_l2_vs_oracle": parity, "launch": "eager" if args.eager else "hipgraph",
             "roofline": roof,
+            "train": train,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2))
