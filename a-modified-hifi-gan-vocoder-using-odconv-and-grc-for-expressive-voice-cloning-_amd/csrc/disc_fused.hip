@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const P* __restrict__ w
   }
 }
 
-template <typename T, int MW, int NB>
-__global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+template <typename T, int NWV, int MW, int NB>
+__global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                        const T* __restrict__ bias, const T* __restrict__ actsave,
                                                        T* __restrict__ y, DcP p) {
   using M = Mma<T>;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const int w0 = blockIdx.x * NB * 16;
-  const int mt0 = (blockIdx.y * 4 + wid) * MW;
+  const int mt0 = (blockIdx.y * NWV + wid) * MW;
   const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
   const int n_mt = p.Cout / 16;
   const int ph = p.kh / 2, pw = p.kw / 2;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, 
   {
     const int cpr = p.Cin * ES / 16;
     const int per = prow * cpr;
-    for (int i = tid; i < p.kh * per; i += 256) {
+    for (int i = tid; i < p.kh * per; i += NWV * 64) {
       const int pl = i / per, rem = i % per;
       const int r = rem / cpr, ch = rem % cpr;
       const int hh = h - ph + pl, ww = w0 - pw + r;
@@ -85,37 +85,36 @@ __global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, 
     for (int n = 0; n < NB; ++n) acc[mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 16;
-  V a_cur[MW], a_nxt[MW];
+  // weight fragments stream L2 -> registers two k-steps ahead of their use (the x tile is already in LDS)
+  V a0[MW], a1[MW], a2[MW];
+  auto wfetch = [&](int kstep, V (&dst)[MW]) {
 #pragma unroll
-  for (int mw = 0; mw < MW; ++mw) {
-    const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
-    a_cur[mw] = M::load_b(wlane + ((long)mt * p.ksteps) * 1024);
-  }
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+      dst[mw] = M::load_b(wlane + ((long)mt * p.ksteps + kstep) * 1024);
+    }
+  };
+  wfetch(0, a0);
+  if (p.ksteps > 1) wfetch(1, a1);
   int tap = 0, c32 = 0;
   for (int kstep = 0; kstep < p.ksteps; ++kstep) {
-    if (kstep + 1 < p.ksteps) {
-#pragma unroll
-      for (int mw = 0; mw < MW; ++mw) {
-        const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
-        a_nxt[mw] = M::load_b(wlane + ((long)mt * p.ksteps + kstep + 1) * 1024);
-      }
-    }
+    if (kstep + 2 < p.ksteps) wfetch(kstep + 2, a2);
     const int ih = tap / p.kw, iw = tap % p.kw;
     const char* bbase = lds + ((long)ih * prow + iw + col) * RS + (c32 * 32 + 8 * g) * ES;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const V bf = M::load_b(bbase + (long)(n * 16) * RS);
 #pragma unroll
-      for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(a_cur[mw], bf, acc[mw][n]);
+      for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(a0[mw], bf, acc[mw][n]);
     }
 #pragma unroll
-    for (int mw = 0; mw < MW; ++mw) a_cur[mw] = a_nxt[mw];
+    for (int mw = 0; mw < MW; ++mw) { a0[mw] = a1[mw]; a1[mw] = a2[mw]; }
     if (++c32 == p.cin32) { c32 = 0; ++tap; }
   }
 
   // ---- epilogue through LDS: [w][rows of this workgroup] -> whole-row stores
   __syncthreads();
-  constexpr int RW = 4 * MW * 16;
+  constexpr int RW = NWV * MW * 16;
   constexpr int ORS = RW * ES + 16;
   const int R0 = blockIdx.y * RW;
 #pragma unroll
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(256) void dconv_cl_kernel(const T* __restrict__ x, 
     constexpr int CPR = RW / EPC;
     T* yrow = y + (((long)b * p.H + h) * p.W) * p.Cout;
     const T* srow = actsave ? actsave + (((long)b * p.H + h) * p.W) * p.Cout : nullptr;
-    for (int i = tid; i < NB * 16 * CPR; i += 256) {
+    for (int i = tid; i < NB * 16 * CPR; i += NWV * 64) {
       const int ch = i % CPR, wi = i / CPR;
       const int ww = w0 + wi, row = R0 + ch * EPC;
       if (ww >= p.W || row >= p.Cout) continue;
@@ -516,20 +515,20 @@ extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int C
   return MV_OK;
 }
 
-template <typename T, int MW, int NB>
+template <typename T, int NWV, int MW, int NB>
 static int dconv_launch(const void* x, const void* wp, const void* bias, const void* actsave, void* y, DcP p, hipStream_t s) {
   using M = Mma<T>;
   const int prow = NB * 16 + p.kw - 1;
   const size_t xb = (size_t)p.kh * prow * (p.Cin * M::ES + 16);
-  const size_t ob = (size_t)NB * 16 * (4 * MW * 16 * M::ES + 16);
+  const size_t ob = (size_t)NB * 16 * (NWV * MW * 16 * M::ES + 16);
   const size_t lds = xb > ob ? xb : ob;
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = dconv_cl_kernel<T, MW, NB>;
+  auto kern = dconv_cl_kernel<T, NWV, MW, NB>;
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
-  dim3 grid(cdiv(p.W, NB * 16), cdiv(p.Cout / 16, 4 * MW), p.B * p.H);
+  dim3 grid(cdiv(p.W, NB * 16), cdiv(p.Cout / 16, NWV * MW), p.B * p.H);
   if (grid.z > 65535) return MV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (const T*)wp, (const T*)bias, (const T*)actsave, (T*)y, p);
+  hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), lds, s, (const T*)x, (const T*)wp, (const T*)bias, (const T*)actsave, (T*)y, p);
   return MV_OK;
 }
 
@@ -541,12 +540,16 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32};
   int rc = MV_ERR_DTYPE;
   MV_DISPATCH(dtype, {
-    if (Cout >= 128) {
-      rc = dconv_launch<T, 2, 8>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
-      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 2, 4>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+    hipStream_t s_ = (hipStream_t)stream;
+    if (Cout >= 256) {        // 8 waves cover all 256 rows: the x tile is staged once per column block
+      rc = dconv_launch<T, 8, 2, 8>(x, packed, bias, act_save, y, p, s_);
+      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 8, 2, 4>(x, packed, bias, act_save, y, p, s_);
+    } else if (Cout >= 128) {
+      rc = dconv_launch<T, 4, 2, 8>(x, packed, bias, act_save, y, p, s_);
+      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 4, 2, 4>(x, packed, bias, act_save, y, p, s_);
     } else {
-      rc = dconv_launch<T, 1, 8>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
-      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 1, 4>(x, packed, bias, act_save, y, p, (hipStream_t)stream);
+      rc = dconv_launch<T, 4, 1, 8>(x, packed, bias, act_save, y, p, s_);
+      if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 4, 1, 4>(x, packed, bias, act_save, y, p, s_);
     }
   });
   if (rc != MV_OK) return rc;

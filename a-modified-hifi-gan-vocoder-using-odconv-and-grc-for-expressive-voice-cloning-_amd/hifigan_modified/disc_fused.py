@@ -8,6 +8,7 @@ fp32 storage keeps using the generic kernels (functional.disc2d / disc1d).
 """
 from __future__ import annotations
 
+import weakref
 from ctypes import c_void_p
 
 import torch
@@ -20,35 +21,49 @@ _P = lambda t: None if t is None else c_void_p(t.data_ptr())
 
 
 class _PackCache:
+    """Packed weights per (parameter, dtype, kind).  Entries are validated against the LIVE parameter object through a
+    weak reference (Python ids and device addresses are recycled once a module is freed) plus its version / the
+    parameter epoch, so a freed module can never alias another one's packed buffer."""
+
     def __init__(self):
         self.d = {}
 
-    def get(self, w, dtype, flip):
-        key = (id(w), dtype, flip)
-        ver = (w._version, ops.param_epoch(), w.data_ptr())
+    def _lookup(self, param, kind):
+        key = (id(param), kind)
+        ver = (param._version, ops.param_epoch(), param.data_ptr())
         hit = self.d.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None and hit[0]() is param and hit[1] == ver:
+            return key, ver, hit[2]
+        return key, ver, None
+
+    def _store(self, key, param, ver, buf):
+        if len(self.d) > 1024:
+            self.d = {k: e for k, e in self.d.items() if e[0]() is not None}
+        self.d[key] = (weakref.ref(param), ver, buf)
+        return buf
+
+    def get(self, param, dtype, flip):
+        key, ver, buf = self._lookup(param, (dtype, flip))
+        if buf is not None:
+            return buf
+        w = _as4d(param)
         Cout, Cin, kh, kw = w.shape
         buf = torch.empty(N.lib().mv_dconv_packed_bytes(Cout, Cin, kh, kw, ops._DT[dtype]), dtype=torch.uint8, device=w.device)
         wd = w.detach().contiguous()
         N.call("mv_dconv_pack", _P(wd), ops._DT[wd.dtype], _P(buf), Cout, Cin, kh, kw, int(flip), ops._DT[dtype], ops._stream())
-        self.d[key] = (ver, buf)
-        return buf
+        return self._store(key, param, ver, buf)
 
-    def head(self, w):
-        """[1,C,kh,kw] -> fp32 [kh*kw][C]."""
-        key = (id(w), "head")
-        ver = (w._version, ops.param_epoch(), w.data_ptr())
-        hit = self.d.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+    def head(self, param):
+        """[1,C,kh,kw] (or [1,C,k]) -> fp32 [taps][C]."""
+        key, ver, buf = self._lookup(param, "head")
+        if buf is not None:
+            return buf
+        w = _as4d(param)
         C, taps = w.shape[1], w.shape[2] * w.shape[3]
         wt = torch.empty(taps, C, device=w.device, dtype=torch.float32)
         wd = w.detach().contiguous()
         N.call("mv_conv_out_pack", _P(wd), ops._DT[wd.dtype], _P(wt), C, taps, ops._stream())
-        self.d[key] = (ver, wt)
-        return wt
+        return self._store(key, param, ver, wt)
 
 
 _packs = _PackCache()
@@ -70,22 +85,22 @@ class _DiscStack(Function):
         H, W = (x0.shape[2], x0.shape[3]) if x0.dim() == 4 else (1, x0.shape[2])
         kh, kw = ws[0].shape[2], ws[0].shape[3]
         st, dev = ops._stream, x0.device
-        cast = lambda t: ops._ParamCache.get(_cache, t, dt)
+        cast = lambda t: _cache.get(t, dt)
         acts = []
         C1 = ws[0].shape[0]
         a = torch.empty(B, H, W, C1, device=dev, dtype=dt)
-        N.call("mv_dfirst_fwd_cl", _P(x0), _P(cast(ws[0])), _P(cast(bs[0])), _P(a), B, H, W, C1, kh, kw, float(slope), ops._dt(x0), st())
+        N.call("mv_dfirst_fwd_cl", _P(x0), _P(cast(params[0])), _P(cast(bs[0])), _P(a), B, H, W, C1, kh, kw, float(slope), ops._dt(x0), st())
         acts.append(a)
         for li in (1, 2, 3):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             y = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
-            N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(ws[li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
+            N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(params[2 * li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
                    kh, kw, N.ACT_LRELU, float(slope), ops._dt(x0), st())
             acts.append(y)
         C4 = ws[4].shape[1]
         out = torch.empty((B, 1, H, W) if x0.dim() == 4 else (B, 1, W), device=dev, dtype=dt)
         bias5 = float(bs[4].detach().float().item()) if not hasattr(bs[4], "_mv_host") else bs[4]._mv_host
-        N.call("mv_dhead_fwd", _P(acts[-1]), _P(_packs.head(ws[4])), bias5, _P(out), B, H, W, C4, kh, kw, ops._dt(x0), st())
+        N.call("mv_dhead_fwd", _P(acts[-1]), _P(_packs.head(params[8])), bias5, _P(out), B, H, W, C4, kh, kw, ops._dt(x0), st())
         ctx.geom = (B, H, W, kh, kw, float(slope), x0.dim())
         ctx.save_for_backward(x0, *acts, *params)
         return out
@@ -113,7 +128,7 @@ class _DiscStack(Function):
             N.call("mv_ntc_to_nct", _P(gwt), _P(gw5), 1, C4, kh * kw, N.MV_F32, st())
             grads[8], grads[9] = to(gw5, params[8]), to(gb5, params[9])
         g = torch.empty(B, H, W, C4, device=dev, dtype=dt)
-        N.call("mv_dhead_dgrad", _P(gy), _P(_packs.head(ws[4])), _P(acts[3]), _P(g), B, H, W, C4, kh, kw, slope, ops._dt(gy), st())
+        N.call("mv_dhead_dgrad", _P(gy), _P(_packs.head(params[8])), _P(acts[3]), _P(g), B, H, W, C4, kh, kw, slope, ops._dt(gy), st())
         # ---- wide layers 4, 3, 2 (indices 3, 2, 1)
         for li in (3, 2, 1):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
@@ -124,7 +139,7 @@ class _DiscStack(Function):
                 N.call("mv_colsum_cl", _P(g), _P(gb), B * H * W, Cout, ops._dt(g), st())
                 grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])
             gprev = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
-            N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(ws[li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,
+            N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(params[2 * li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,
                    kh, kw, N.ACT_NONE, slope, ops._dt(g), st())
             g = gprev
         # ---- first layer
@@ -136,7 +151,7 @@ class _DiscStack(Function):
         gx0 = None
         if need[0]:
             gx0 = torch.empty_like(x0)
-            N.call("mv_dfirst_dgrad_cl", _P(g), _P(ops._ParamCache.get(_cache, ws[0], dt)), _P(gx0), B, H, W, C1, kh, kw, ops._dt(g), st())
+            N.call("mv_dfirst_dgrad_cl", _P(g), _P(_cache.get(params[0], dt)), _P(gx0), B, H, W, C1, kh, kw, ops._dt(g), st())
         return (gx0, None, *grads)
 
 

@@ -200,7 +200,7 @@ def main():
             Bd, Hd, Wd = 2 * B, 2, Tm * 256 // 2
             xin = torch.randn(Bd, Hd, Wd, 128, device=dev).to(tdtype)
             yout = torch.empty(Bd, Hd, Wd, 256, device=dev, dtype=tdtype)
-            pk = _df._packs.get(conv.weight, tdtype, 0)
+            pk = _df._packs.get(conv.weight, tdtype, 0)   # keyed on the live parameter
             bias = conv.bias.detach().to(tdtype)
             P = lambda t: ctypes.c_void_p(t.data_ptr())
             def run():
