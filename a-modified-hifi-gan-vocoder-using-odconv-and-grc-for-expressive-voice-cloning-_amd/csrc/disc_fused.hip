@@ -488,6 +488,22 @@ __global__ __launch_bounds__(256) void colsum_cl_kernel(const T* __restrict__ x,
   }
 }
 
+// out[row] = x[row][c]  /  y[row][:] = 0, y[row][c] = g[row]   (the C -> 1 head rides the MFMA conv with zero-padded channels)
+template <typename T>
+__global__ __launch_bounds__(256) void take_channel_kernel(const T* __restrict__ x, T* __restrict__ out, long rows, int C, int c) {
+  for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) out[r] = x[r * C + c];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void put_channel_kernel(const T* __restrict__ g, T* __restrict__ y, long rows, int C, int c) {
+  const long n = rows * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C;
+    const int ch = (int)(i % C);
+    T z; st<T>(&z, 0.f);
+    y[i] = (ch == c) ? g[r] : z;
+  }
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -677,6 +693,23 @@ extern "C" int mv_colsum_cl(const void* x, float* out, long rows, int C, int dty
   const int chunk = 2048;
   MV_DISPATCH(dtype, hipLaunchKernelGGL(colsum_cl_kernel<T>, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)x, out, rows, C, chunk));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_take_channel(const void* x, void* out, long rows, int C, int c, int dtype, void* stream) {
+  MV_CHECK_ARG(x && out && rows > 0 && C > 0 && c >= 0 && c < C);
+  const int grid = (int)((rows + 255) / 256 > 4096 ? 4096 : (rows + 255) / 256);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(take_channel_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, rows, C, c));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_put_channel(const void* g, void* y, long rows, int C, int c, int dtype, void* stream) {
+  MV_CHECK_ARG(g && y && rows > 0 && C > 0 && c >= 0 && c < C);
+  const long n = rows * C;
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(put_channel_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)g, (T*)y, rows, C, c));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -293,6 +293,11 @@ int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int
 /* out[c] = sum over rows of x[row][c] (bias gradient of a channels-last tensor); C divides 256. */
 int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream);
 
+/* Channel extract / insert for channels-last tensors: out[row] = x[row][c];  y[row][:] = 0, y[row][c] = g[row].
+ * Lets the Cout = 1 head use the MFMA convolution with zero-padded channels. */
+int mv_take_channel(const void* x, void* out, long rows, int C, int c, int dtype, void* stream);
+int mv_put_channel(const void* g, void* y, long rows, int C, int c, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
