@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void odconv_pack_kernel(const P* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <typename T, int S, int MW, int NB, bool PF>
+template <typename T, int S, int MW, int NB, bool PF, int KB>
 __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                         const T* __restrict__ bias, const float* __restrict__ alpha_in,
                                                         const float* __restrict__ pooled_in, const T* __restrict__ att_w,
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   using WL = WLoad<T>;
   constexpr int ES = M::ES;
   extern __shared__ __align__(16) char lds[];
-  float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha
+  float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha (KB <= OD_MAXK banks used)
   char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
   const int RS = p.Cin * ES + 16;
 
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   }
   __syncthreads();
 
-  float al[S][OD_MAXK];
+  float al[S][KB];
 #pragma unroll
   for (int s = 0; s < S; ++s)
 #pragma unroll
-    for (int kb = 0; kb < OD_MAXK; ++kb) al[s][kb] = kb < p.K ? alds[s * OD_MAXK + kb] : 0.f;
+    for (int kb = 0; kb < KB; ++kb) al[s][kb] = kb < p.K ? alds[s * OD_MAXK + kb] : 0.f;
 
   f32x4 acc[S][MW][NB];
 #pragma unroll
@@ -184,22 +184,22 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   const int cpc = p.Cin / 8;
   const long bank_stride = (long)n_mt * p.ksteps * 512 * ES;     // bytes between banks
   const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 8 * ES;
-  auto wload = [&](int kstep, typename WL::R (&dst)[MW][OD_MAXK]) {
+  auto wload = [&](int kstep, typename WL::R (&dst)[MW][KB]) {
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw) {
       const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);   // clamp: out-of-range tiles compute garbage that is never stored
       const char* wbase = wlane + ((long)mt * p.ksteps + kstep) * 512 * ES;
 #pragma unroll
-      for (int kb = 0; kb < OD_MAXK; ++kb)
+      for (int kb = 0; kb < KB; ++kb)
         if (kb < p.K) dst[mw][kb] = WL::load(wbase + kb * bank_stride);
     }
   };
-  typename WL::R wr[MW][OD_MAXK];
+  typename WL::R wr[MW][KB];
   wload(0, wr);
   int tap = 0, c8 = g;                                           // this lane's chunk (4*kstep + g) as (tap, c8)
   while (c8 >= cpc) { c8 -= cpc; ++tap; }
   for (int kstep = 0; kstep < p.ksteps; ++kstep) {
-    typename WL::R wn[MW][OD_MAXK];
+    typename WL::R wn[MW][KB];
     if (PF && kstep + 1 < p.ksteps) wload(kstep + 1, wn);        // next fragments travel L2 -> registers under this step's math
     // per-sample kernels for this k-step: sum_kb alpha[s,kb] * W[kb]  (fp32, then one rounding to the operand type)
     V afr[S][MW];
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       for (int s = 0; s < S; ++s) {
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < OD_MAXK; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
           if (kb < p.K) WL::fma8(wr[mw][kb], al[s][kb], f);
         afr[s][mw] = make_a<T>(f);
       }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-          for (int kb = 0; kb < OD_MAXK; ++kb)
+          for (int kb = 0; kb < KB; ++kb)
             if (kb < p.K) wr[mw][kb] = wn[mw][kb];
       }
     } else if (kstep + 1 < p.ksteps) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   }
 }
 
-template <typename T, int S, int MW, int NB>
+template <typename T, int S, int MW, int NB, bool PFW, int KB>
 static int od_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
                      const void* att_w, const void* att_b, const void* film, void* y, float* pooled_out, OdP p,
                      hipStream_t stream) {
@@ -333,7 +333,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
   const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
   const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = odconv_cl_kernel<T, S, MW, NB, (M::ES == 2)>;
+  auto kern = odconv_cl_kernel<T, S, MW, NB, (PFW && M::ES == 2), KB>;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -425,7 +425,10 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
   const long wbytes = (long)K * p.M * p.ksteps * 32 * (dtype == MV_F32 ? 4 : 2);
   int rc = MV_ERR_DTYPE;
   hipStream_t st_ = (hipStream_t)stream;
-#define OD_GO(S_, MW_, NB_) rc = od_launch<T, S_, MW_, NB_>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_)
+#define OD_GO(S_, MW_, NB_) do { \
+    if (K <= 4 && p.ksteps <= 8) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
+    else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
+    else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); } while (0)
   MV_DISPATCH(dtype, {
     if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler): share bank loads over 2 samples
       OD_GO(2, 1, 3);
