@@ -52,7 +52,7 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   using V = typename M::V;
   constexpr int ES = M::ES;
   extern __shared__ __align__(16) char lds[];
-  const int RS = p.Cin * ES + 16;
+  const int RS = lds_row_stride(p.Cin * ES, ES);
   const int prow = NB * 16 + p.kw - 1;          // staged columns per plane
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
@@ -535,7 +535,7 @@ template <typename T, int NWV, int MW, int NB>
 static int dconv_launch(const void* x, const void* wp, const void* bias, const void* actsave, void* y, DcP p, hipStream_t s) {
   using M = Mma<T>;
   const int prow = NB * 16 + p.kw - 1;
-  const size_t xb = (size_t)p.kh * prow * (p.Cin * M::ES + 16);
+  const size_t xb = (size_t)p.kh * prow * lds_row_stride(p.Cin * M::ES, M::ES);
   const size_t ob = (size_t)NB * 16 * (NWV * MW * 16 * M::ES + 16);
   const size_t lds = xb > ob ? xb : ob;
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;

@@ -162,4 +162,16 @@ template <> struct PackW<float> {
 
 constexpr int FRAG_BYTES = 1024;  // one 16x32 operand image: 64 lanes x 16 bytes
 
+// LDS row stride (bytes) for a channels-last operand tile read with ds_read_b128 by lane (row = lane&15, 16-byte chunk =
+// lane>>4): brute force over the b128 lane groups shows the read is conflict-free iff stride % 128 is 32 or 96
+// (16-bit storage); +16 is 2-way.  fp32 rows (two b128 per lane) stay at +16.
+__host__ __device__ inline int lds_row_stride(int row_bytes, int elem_size) {
+  if (elem_size != 2) return row_bytes + 16;
+  for (int pad = 16; pad <= 128; pad += 16) {
+    const int m = (row_bytes + pad) % 128;
+    if (m == 32 || m == 96) return row_bytes + pad;
+  }
+  return row_bytes + 16;
+}
+
 }  // namespace mv

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha (KB <= OD_MAXK banks used)
   char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
-  const int RS = p.Cin * ES + 16;
+  const int RS = lds_row_stride(p.Cin * ES, ES);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
@@ -329,7 +329,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
                      hipStream_t stream) {
   using M = Mma<T>;
   p.nrows = NB * 16 + (p.ntaps - 1) * (p.transposed ? 1 : p.dil);
-  const size_t xbytes = (size_t)S * p.nrows * (p.Cin * M::ES + 16);
+  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
   const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
   const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
