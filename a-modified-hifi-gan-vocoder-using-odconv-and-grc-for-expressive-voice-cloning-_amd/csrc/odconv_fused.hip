@@ -218,14 +218,18 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
     const int shift = p.transposed ? -tap : (tap * p.dil - p.pad);
     const int rbase = kvalid ? (shift - p.shift_lo + col) : col;
     const int coff = kvalid ? c8 * 8 * ES : 0;
+    const int bbase = rbase * RS + coff;             // 32-bit LDS offsets
 #pragma unroll
-    for (int s = 0; s < S; ++s)
+    for (int s = 0; s < S; ++s) {
+      // all B fragments of this sample first (independent LDS reads in flight together), then the MFMAs
+      V bfr[NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const V bf = M::load_b(xl + ((long)s * p.nrows + rbase + n * 16) * RS + coff);
+      for (int n = 0; n < NB; ++n) bfr[n] = M::load_b(xl + (s * p.nrows * RS + bbase + n * 16 * RS));
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw) acc[s][mw][n] = M::mma(afr[s][mw], bf, acc[s][mw][n]);
-      }
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw) acc[s][mw][n] = M::mma(afr[s][mw], bfr[n], acc[s][mw][n]);
+    }
     if (PF) {
       if (kstep + 1 < p.ksteps) {
 #pragma unroll
@@ -321,6 +325,247 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ K-loop variant
+// Short sequences with big kernel banks (the first upsampler: 33 columns per sample, 16.8 MB of banks): aggregating the
+// per-sample kernel costs more than the convolution itself.  Here the banks are used AS STORED - exactly the reference's
+// loop over k (odconv.py:187-204): D_k = W_k * x accumulates in a scratch accumulator, out += alpha[b,k] * D_k once per
+// bank.  4x the MFMA work of the aggregated form, but zero aggregation VALU and every weight fragment is loaded once
+// per S=4 samples (weights-stationary), two k-steps ahead of its use.
+template <typename T, int S, int NB, int KB>
+__global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                           const T* __restrict__ bias, const float* __restrict__ alpha_in,
+                                                           const float* __restrict__ pooled_in, const T* __restrict__ att_w,
+                                                           const T* __restrict__ att_b, T* __restrict__ y,
+                                                           float* __restrict__ pooled_out, OdP p) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int ES = M::ES;
+  extern __shared__ __align__(16) char lds[];
+  float* alds = reinterpret_cast<float*>(lds);
+  char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
+  const int RS = lds_row_stride(p.Cin * ES, ES);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int mt = blockIdx.x * 4 + wid;
+  const int b0 = blockIdx.y * S;
+  const int n_mt = p.M / 16;
+  const int ZR = p.nrows - 1;                      // index of the all-zero row
+
+  // ---- alpha (odconv.py:36-40)
+  if (alpha_in) {
+    if (tid < S * p.K) {
+      const int s = tid / p.K, kb = tid % p.K;
+      alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
+    }
+  } else {
+    for (int pr = wid; pr < S * p.K; pr += 4) {
+      const int s = pr / p.K, kb = pr % p.K;
+      float acc = 0.f;
+      if (b0 + s < p.B)
+        for (int c = lane; c < p.Cin; c += 64) acc += ld<T>(att_w + (long)kb * p.Cin + c) * pooled_in[(long)(b0 + s) * p.Cin + c];
+      acc = wave_sum(acc);
+      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+    }
+    __syncthreads();
+    if (tid < S) {
+      float m = -INFINITY, den = 0.f;
+      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
+      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
+      for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
+    }
+  }
+  // ---- stage the whole (short) input of every sample: row r <-> input step r + shift_lo, last row = zeros
+  {
+    const int cpr = p.Cin * ES / 16;
+    const int per = p.nrows * cpr;
+    for (int i = tid; i < S * per; i += 256) {
+      const int s = i / per, rem = i % per;
+      const int r = rem / cpr, ch = rem % cpr;
+      const int tin = p.shift_lo + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
+      *reinterpret_cast<u32x4*>(xl + ((long)s * p.nrows + r) * RS + ch * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  // one accumulator set PER BANK, touched only by MFMA until the end (they stay in AGPRs; at one wave per SIMD the
+  // register file has room for KB*S*NB*4 = 192 of them), then out = sum_kb alpha[b,kb] * acc[kb]
+  f32x4 acc[KB][S][NB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[kb][s][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int mtc = mt < n_mt ? mt : n_mt - 1;
+  const long bank_stride = (long)n_mt * p.ksteps * 512 * ES;
+  const char* wlane = reinterpret_cast<const char*>(wp) + ((long)mtc * p.ksteps * 512 + lane * 8) * ES;
+  const int total = p.K * p.ksteps;
+  // PD-deep register ring with STATIC slots (ksteps % PD == 0): one wave per SIMD has to cover L2 latency itself.
+  // The prefetch cursor (bank, k-step) advances incrementally - no integer division in the loop.
+  constexpr int PD = 8;
+  V ring[PD];
+  const char* wcur = wlane;                          // address of fragment `fetched`
+  int fetched = 0, fks = 0;
+  auto wnext = [&]() {
+    const V r = M::load_b(wcur);
+    ++fetched;
+    if (++fks == p.ksteps) { fks = 0; wcur += bank_stride - (long)(p.ksteps - 1) * 512 * ES; }
+    else wcur += 512 * ES;
+    return r;
+  };
+#pragma unroll
+  for (int i = 0; i < PD; ++i) ring[i] = (fetched < total) ? wnext() : ring[0];
+  // per-lane LDS byte offsets of the B operand for each of the (at most two) taps and column tiles, clamped to the zero row
+  const int cpc = p.Cin / 8;                         // multiple of 4 here: a k-step never straddles two taps
+  const int sample_stride = p.nrows * RS;
+  unsigned lbase[2][NB];
+#pragma unroll
+  for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int shift = p.transposed ? -tp : (tp * p.dil - p.pad);
+      int r = col - p.shift_lo + n * 16 + shift;
+      r = r < ZR ? r : ZR;
+      lbase[tp][n] = (unsigned)(r * RS + g * 8 * ES);
+    }
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb < p.K) {
+      for (int ks0 = 0; ks0 < p.ksteps; ks0 += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+          const int ks = ks0 + j;
+          const V a0 = ring[j];
+          if (fetched < total) ring[j] = wnext();
+          const int tap = (4 * ks >= cpc) ? 1 : 0;                  // wave-uniform (ntaps <= 2)
+          const unsigned koff = (unsigned)((4 * ks - tap * cpc) * 8 * ES);
+          // all B fragments first (independent LDS reads in flight together), then the MFMAs
+          V bfr[S][NB];
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              bfr[s][n] = M::load_b(xl + ((tap ? lbase[1][n] : lbase[0][n]) + (unsigned)(s * sample_stride) + koff));
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[kb][s][n] = M::mma(a0, bfr[s][n], acc[kb][s][n]);
+        }
+      }
+    }
+  }
+  f32x4 out[S][NB];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      out[s][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+        if (kb < p.K) {
+          const float al = alds[s * OD_MAXK + kb];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) out[s][n][i] += al * acc[kb][s][n][i];
+        }
+    }
+
+  // ---- epilogue: bias, activation -> LDS tile [s][q][64 rows] -> whole-row stores
+  __syncthreads();
+  constexpr int RW = 64;
+  constexpr int ORS = RW * ES + 16;
+  char* ol = xl;
+  const int R0 = blockIdx.x * RW;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int b = b0 + s;
+    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (mt < n_mt && b < p.B) {
+      const int row = 16 * mt + 4 * g;
+      const int r = p.transposed ? row / p.Cout : 0;
+      const int o = p.transposed ? row % p.Cout : row;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias)
+        for (int k2 = 0; k2 < p.K; ++k2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bv[i] += alds[s * OD_MAXK + k2] * ld<T>(bias + (long)k2 * p.Cout + o + i);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const int q = n * 16 + col;
+        const int u = p.transposed ? q * p.stride + r - p.pad : q;
+        const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+        float ov[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ov[i] = apply_act(out[s][n][i] + bv[i], p.act, p.slope);
+          if (ok) rowsum[i] += M::round_store(ov[i]);
+        }
+        M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+      }
+    }
+    if (pooled_out) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = rowsum[i];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+        rowsum[i] = v;
+      }
+      if (col == 0 && mt < n_mt && b < p.B) {
+        const int row = 16 * mt + 4 * g;
+        const int o = p.transposed ? row % p.Cout : row;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int EPC = 16 / ES;
+    constexpr int CPR = RW / EPC;
+    const int totalc = S * NB * 16 * CPR;
+    for (int i = tid; i < totalc; i += 256) {
+      const int ch = i % CPR, qi = (i / CPR) % (NB * 16), s = i / (CPR * NB * 16);
+      const int b = b0 + s, row = R0 + ch * EPC;
+      if (b >= p.B || qi >= p.nq || row >= p.M) continue;
+      const int r = p.transposed ? row / p.Cout : 0;
+      const int o = p.transposed ? row % p.Cout : row;
+      const int u = p.transposed ? qi * p.stride + r - p.pad : qi;
+      if (u < 0 || u >= p.Tout) continue;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)(s * NB * 16 + qi)) * ORS + ch * 16);
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
+    }
+  }
+}
+
+template <typename T, int S, int NB>
+static int od_kloop_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
+                           const void* att_w, const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream) {
+  using M = Mma<T>;
+  if (p.nq > NB * 16 || p.K > 4 || p.Cin % 32 || p.ksteps % 8 || p.nchunks != 4 * p.ksteps || p.ntaps > 2)
+    return MV_ERR_UNSUPPORTED;
+  // rows: every input step that any column can touch (shift_lo .. Tin-1 shifted) + one zero row
+  p.nrows = p.Tin - p.shift_lo + 1;
+  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
+  const size_t obytes = (size_t)S * NB * 16 * (64 * M::ES + 16);
+  const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = odconv_kloop_kernel<T, S, NB, 4>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  dim3 grid(cdiv(p.M / 16, 4), cdiv(p.B, S));
+  if (grid.y > 65535) return MV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
+                     (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p);
+  return MV_OK;
 }
 
 template <typename T, int S, int MW, int NB, bool PFW, int KB>
@@ -430,8 +675,14 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
     else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
     else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); } while (0)
   MV_DISPATCH(dtype, {
-    if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler): share bank loads over 2 samples
-      OD_GO(2, 1, 3);
+    if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler)
+      rc = MV_ERR_UNSUPPORTED;
+      if (!film_proj && dtype != MV_F32 && wbytes > (4 << 20) && B >= 2)   // K-loop, weights-stationary over S samples
+      {   // S = 2 measured best (two workgroups per CU overlap each other's LDS/L2 latency); S = 1 if the tiles do not fit
+        rc = od_kloop_launch<T, 2, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+        if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+      }
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(2, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else if (wbytes > (1 << 20)) {         // big kernels, medium sequences: 144-column blocks amortise the aggregation
       OD_GO(1, 2, 9);

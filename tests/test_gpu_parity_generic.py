@@ -324,3 +324,30 @@ def test_generator_fused_pipeline_every_stage(H, dtype):
     assert ew < wave_bound, f"wave {dtype}: {ew:.2e} (generic path {eg:.2e})"
     # fewer stored roundings: the fused path must not be less accurate than the generic one (with slack for noise)
     assert ew < 1.5 * eg + 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T", [(5, 32), (8, 20), (4, 40)])
+def test_odconv_kloop_first_upsampler(H, dtype, B, T):
+    """K-loop weights-stationary kernel (odconv_kloop_kernel: banks used as stored, alpha applied to the accumulators)
+    at the first upsampler's geometry, ragged sample groups, vs the generic fp32 HIP kernel."""
+    from hifigan_modified import functional as Fn, ops
+    from hifigan_modified import _native as N
+    from hifigan_modified.fused import OdconvFused
+    torch.manual_seed(7)
+    m = H.ODConvTranspose1d(512, 256, 16, stride=8, padding=4).cuda()
+    with torch.no_grad():
+        m.bias.copy_(torch.randn_like(m.bias) * 0.5)
+    x32 = torch.randn(B, 512, T, device="cuda")
+    x = x32.to(dtype)
+    fz = OdconvFused(m)
+    with torch.no_grad():
+        ref = m(x32, act="lrelu").cpu()
+        pooled = x.float().sum(dim=2).contiguous()
+        pout = torch.zeros(B, 256, device="cuda")
+        y = ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x), Fn._cache, pooled_in=pooled, pooled_out=pout, act=N.ACT_LRELU))
+    bound = {torch.float16: 1.5e-3, torch.bfloat16: 8e-3}[dtype]
+    assert y.shape == ref.shape
+    e = O.rel_l2(y.float().cpu(), ref)
+    assert e < bound, f"kloop {dtype} B={B} T={T}: {e:.2e}"
+    assert O.rel_l2(pout.cpu(), y.float().sum(dim=2).cpu()) < 1e-4
