@@ -272,16 +272,20 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       const int off = meta.tap_off[tap];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        V bf[NTW];
+        // every operand of this k-step first (independent LDS reads in flight together), then the MFMAs
+        V bf[NTW], af[4];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16 + off) * RS + ks * 32 * ES);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int fo = meta.frag_of[m][tap];
-          if (fo >= 0) {
-            const V a = M::load_a(wl + (size_t)(fo * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+          af[m] = M::load_a(wl + (size_t)((fo >= 0 ? fo : 0) * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+        }
 #pragma unroll
-            for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
+        for (int m = 0; m < 4; ++m) {
+          if (meta.frag_of[m][tap] >= 0) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(af[m], bf[n], v[m][n]);
           }
         }
       }
@@ -320,15 +324,15 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      V bf[NTW];
+      V bf[NTW], af[4];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16) * RS + ks * 32 * ES);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+      for (int m = 0; m < 4; ++m) af[m] = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(a, bf[n], v[m][n]);
-      }
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(af[m], bf[n], v[m][n]);
     }
 
     // ---- stage 3: f[co][t] = b_fus + sum_cc W_fus[co][cc] c[cc][t]   (c fed straight from the accumulators)
@@ -344,12 +348,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       V cb[NTW];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) cb[n] = M::from_acc(v[2 * s][n], v[2 * s + 1][n]);
+      V af[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const V a = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
+      for (int m = 0; m < 4; ++m) af[m] = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(a, cb[n], f[m][n]);
-      }
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(af[m], cb[n], f[m][n]);
     }
 
     if (PASS == 2) {
