@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
                                                            float* __restrict__ gw, float* __restrict__ galpha,
                                                            int B, int Cin, int Tin, int Cout, int Tout, int ks,
                                                            int stride, int pad, int dil, int nbanks,
-                                                           long x_bs, long x_cs, long g_bs, long g_cs, int tsplit, int tchunk) {
+                                                           long x_bs, long x_cs, long g_bs, long g_cs, int tsplit, int tchunk,
+                                                           int per_sample) {
   // grid.z = B * tsplit: every workgroup reduces one (sample, time chunk) and adds its tile with fp32 atomics
   extern __shared__ __align__(16) float sm[];
   const int xw = (WG_TT - 1) * stride + (ks - 1) * dil + 1;
@@ -72,7 +73,14 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
     __syncthreads();
   }
   const bool ok = o < Cout && c < Cin;
-  if (nbanks == 1) {
+  if (per_sample) {           // gw = per-sample tiles [B][Cout][Cin][ks]; the alpha chain is applied by odconv_wgrad_reduce_kernel
+    if (ok) {
+      float* gwk = gw + (long)b * wbank + ((long)o * Cin + c) * ks;
+#pragma unroll
+      for (int j = 0; j < WG_MAXKS; ++j)
+        if (j < ks) { if (tsplit == 1) gwk[j] = acc[j]; else atomicAdd(gwk + j, acc[j]); }
+    }
+  } else if (nbanks == 1) {
     if (ok) {
       float* gwk = gw + ((long)o * Cin + c) * ks;
 #pragma unroll
@@ -94,6 +102,41 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(const T* __restrict__
       if (tid == 0) atomicAdd(galpha + b * nbanks + k, dot);
     }
   }
+}
+
+// ODConv bank gradients from per-sample tiles: gw[k][e] = sum_b alpha[b,k] gws[b][e];
+// galpha[b,k] += <gws[b], w[k]>.  One thread per weight element e, a block covers `epb` elements.
+template <typename T>
+__global__ __launch_bounds__(256) void odconv_wgrad_reduce_kernel(const float* __restrict__ gws, const T* __restrict__ w,
+                                                                  const float* __restrict__ alpha, float* __restrict__ gw,
+                                                                  float* __restrict__ galpha, int B, int K, long nelem, int epb) {
+  extern __shared__ float dots[];              // [B][K] block-local <gws[b], w[k]>
+  for (int i = threadIdx.x; i < B * K; i += blockDim.x) dots[i] = 0.f;
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * epb;
+  const int lane = threadIdx.x & 63;
+  for (long e = e0 + threadIdx.x; e < e0 + epb; e += blockDim.x) {
+    const bool ok = e < nelem;
+    float wk[8], acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { wk[k] = (ok && k < K) ? ld<T>(w + (long)k * nelem + e) : 0.f; acc[k] = 0.f; }
+    for (int b = 0; b < B; ++b) {
+      const float g = ok ? gws[(long)b * nelem + e] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < K) {
+          acc[k] += alpha[b * K + k] * g;
+          const float d = wave_sum(g * wk[k]);
+          if (lane == 0) atomicAdd(dots + b * K + k, d);
+        }
+    }
+    if (ok)
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k < K) gw[(long)k * nelem + e] = acc[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B * K; i += blockDim.x) atomicAdd(galpha + i, dots[i]);
 }
 
 // rowsum[b][o] = sum_t gy[b,o,t]
@@ -378,15 +421,19 @@ extern "C" int mv_act_bwd(const void* gy, const void* y, void* gx, long n, int a
   return MV_OK;
 }
 
+extern "C" size_t mv_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int ks, int nbanks) {
+  return nbanks > 1 ? sizeof(float) * (size_t)B * Cout * Cin * ks : 0;
+}
+
 extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, const float* alpha, float* gw, float* galpha,
-                               int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
-                               int nbanks, long x_bs, long x_cs, long g_bs, long g_cs, int dtype, void* stream) {
+                               float* workspace, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad,
+                               int dil, int nbanks, long x_bs, long x_cs, long g_bs, long g_cs, int dtype, void* stream) {
   MV_CHECK_ARG(x && gy && gw && B > 0 && Cin > 0 && Cout > 0 && Tin > 0 && Tout > 0 && ks > 0 && ks <= WG_MAXKS);
-  MV_CHECK_ARG(nbanks >= 1 && nbanks <= 8 && (nbanks == 1 || (alpha && galpha && w)));
+  MV_CHECK_ARG(nbanks >= 1 && nbanks <= 8 && (nbanks == 1 || (alpha && galpha && w && workspace)));
   const int xw = (WG_TT - 1) * stride + (ks - 1) * dil + 1;
   const size_t lds = sizeof(float) * (16 * xw + 16 * WG_TT + 32);
   if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
-  // split time so that ~2048 workgroups exist; every workgroup adds its partial tile atomically
+  // split time so that ~2048 workgroups exist; partial tiles are combined with fp32 atomics
   const int tiles = cdiv(Cin, 16) * cdiv(Cout, 16);
   int tsplit = cdiv(2048, tiles * B);
   const int max_split = cdiv(Tout, WG_TT);
@@ -396,10 +443,23 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
   tsplit = cdiv(Tout, tchunk);
   if ((long)B * tsplit > 65535) return MV_ERR_UNSUPPORTED;
   dim3 grid(cdiv(Cin, 16), cdiv(Cout, 16), B * tsplit);
-  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)nbanks * Cout * Cin * ks, (hipStream_t)stream);
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(conv1d_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x,
-                                        (const T*)gy, (const T*)w, alpha, gw, galpha, B, Cin, Tin, Cout, Tout, ks,
-                                        stride, pad, dil, nbanks, x_bs, x_cs, g_bs, g_cs, tsplit, tchunk));
+  const long nelem = (long)Cout * Cin * ks;
+  const int per_sample = nbanks > 1;
+  float* dst = per_sample ? workspace : gw;
+  // ODConv (nbanks > 1): per-sample tiles first (no cross-sample contention), then one reduction applies the alpha chain
+  if (!per_sample || tsplit > 1)
+    hipMemsetAsync(dst, 0, sizeof(float) * (size_t)(per_sample ? B : 1) * nelem, (hipStream_t)stream);
+  MV_DISPATCH(dtype, {
+    hipLaunchKernelGGL(conv1d_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, (const T*)gy,
+                       (const T*)w, alpha, dst, galpha, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, nbanks, x_bs, x_cs,
+                       g_bs, g_cs, tsplit, tchunk, per_sample);
+    if (per_sample) {
+      const int epb = 4096;
+      hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
+                         sizeof(float) * B * nbanks, (hipStream_t)stream, workspace, (const T*)w, alpha, gw, galpha, B,
+                         nbanks, nelem, epb);
+    }
+  });
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

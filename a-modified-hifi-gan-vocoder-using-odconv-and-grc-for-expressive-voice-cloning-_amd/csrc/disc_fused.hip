@@ -348,18 +348,23 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const T* __restrict__ 
       typename M::V a[2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) a[m] = trload(ga + (size_t)k0 * GRS + m * 32, ga + (size_t)(k0 + 4) * GRS + m * 32);
+      // all transposed B fragments of this position block first (independent LDS reads in flight), then the MFMAs
+      typename M::V bfr[TG][2];
 #pragma unroll
       for (int t = 0; t < TG; ++t) {
-        const int tap = tap0 + t;
-        if (tap < TAPS) {
-          const int ih = tap / TAPS_W, iw = tap % TAPS_W;
-          const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS;
+        const int tap = (tap0 + t) < TAPS ? (tap0 + t) : (TAPS - 1);
+        const int ih = tap / TAPS_W, iw = tap % TAPS_W;
+        const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS;
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const typename M::V bfr = trload(pb + n * 32, pb + 4 * XRS + n * 32);
+        for (int n = 0; n < 2; ++n) bfr[t][n] = trload(pb + n * 32, pb + 4 * XRS + n * 32);
+      }
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[t][m][n] = M::mma(a[m], bfr, acc[t][m][n]);
-          }
+      for (int t = 0; t < TG; ++t) {
+        if (tap0 + t < TAPS) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[t][m][n] = M::mma(a[m], bfr[t][n], acc[t][m][n]);
         }
       }
     }

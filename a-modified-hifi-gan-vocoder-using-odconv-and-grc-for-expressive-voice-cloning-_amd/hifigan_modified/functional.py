@@ -54,13 +54,17 @@ class _ODConv(Function):
     """odconv.py:73-108 / :172-205.  cfg = (transposed, stride, padding, output_padding, dilation, act, slope)."""
 
     @staticmethod
-    def forward(ctx, x, kernels, bias, att_w, att_b, cfg):
+    def forward(ctx, x, kernels, bias, att_w, att_b, cfg, fused=None):
         transposed, stride, padding, out_pad, dilation, act, slope = cfg
         x = x if x.is_contiguous() else x.contiguous()
         K, C = att_w.shape[0], att_w.shape[1]
         wa, wk, wb = _w(att_w, x).view(K, C), _w(kernels, x), _w(bias, x)
         alpha, pooled = ops.odconv_attn(x, wa, _w(att_b, x), want_pooled=True)
-        if transposed:
+        y = None
+        if fused is not None and x.dtype != torch.float32:
+            # 16-bit storage: the forward runs on the fused channels-last MFMA kernel with the alpha computed above
+            y = ops.ntc_to_nct(fused.forward_cl(ops.nct_to_ntc(x), _cache, alpha=alpha, act=act, slope=slope))
+        elif transposed:
             y = ops.conv_transpose1d(x, wk, wb, alpha, stride, padding, out_pad, dilation, act, slope)
         else:
             y = ops.conv1d(x, wk, wb, alpha, stride, padding, dilation, 1, act, slope)
@@ -93,7 +97,7 @@ class _ODConv(Function):
         gb = ops.bias_grad(g, alpha, _w(bias, x), galpha)
         gwa, gba, gm = ops.odconv_attn_bwd(alpha, galpha, pooled, _w(att_w, x).view(K, C), Tin)
         ops.add_rowconst_(gx, gm)          # the pooling path: (1/T) Wa^T gz added to every time step
-        return gx, _to(gw, kernels), _to(gb, bias), _to(gwa, att_w), _to(gba, att_b), None
+        return gx, _to(gw, kernels), _to(gb, bias), _to(gwa, att_w), _to(gba, att_b), None, None
 
 
 def odconv_attention(x, att_w, att_b):
@@ -103,13 +107,14 @@ def odconv_attention(x, att_w, att_b):
         return ops.odconv_attn(x, _w(att_w, x).view(K, C), _w(att_b, x))
 
 
-def odconv1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, dilation=1, act=None, slope=0.1):
-    return _ODConv.apply(x, kernels, bias, att_w, att_b, (False, stride, padding, 0, dilation, _ACT[act], slope))
+def odconv1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, dilation=1, act=None, slope=0.1, fused=None):
+    return _ODConv.apply(x, kernels, bias, att_w, att_b, (False, stride, padding, 0, dilation, _ACT[act], slope), fused)
 
 
 def odconv_transpose1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, output_padding=0, dilation=1,
-                       act=None, slope=0.1):
-    return _ODConv.apply(x, kernels, bias, att_w, att_b, (True, stride, padding, output_padding, dilation, _ACT[act], slope))
+                       act=None, slope=0.1, fused=None):
+    return _ODConv.apply(x, kernels, bias, att_w, att_b, (True, stride, padding, output_padding, dilation, _ACT[act], slope),
+                         fused)
 
 
 # ----------------------------------------------------------------------------------------------- plain convolutions

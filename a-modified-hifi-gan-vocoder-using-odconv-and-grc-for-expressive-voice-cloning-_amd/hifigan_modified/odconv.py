@@ -52,6 +52,16 @@ class _ODConvBase(nn.Module):
         for name in ("spatial_attention", "in_channel_attention", "out_channel_attention"):
             yield from getattr(self, name).parameters()
 
+    def _fused(self):
+        """Channels-last MFMA launcher of this layer (None when the geometry is outside the fused kernel's support)."""
+        f = getattr(self, "_mv_fused", None)
+        if f is None:
+            from .fused import OdconvFused
+            f = OdconvFused(self)
+            f = f if f.supported() else False
+            object.__setattr__(self, "_mv_fused", f)
+        return f or None
+
     def attention(self, x):
         """alpha [B,K] (fp32) = softmax_K(Conv1x1(mean_t x))."""
         att = self.kernel_attention[1]
@@ -72,7 +82,7 @@ class ODConv1d(_ODConvBase):
     def forward(self, x, act=None, slope=0.1):
         att = self.kernel_attention[1]
         return Fn.odconv1d(x, self.kernels, self.bias, att.weight, att.bias, self.stride, self.padding,
-                           self.dilation, act, slope)
+                           self.dilation, act, slope, fused=self._fused())
 
 
 class ODConvTranspose1d(_ODConvBase):
@@ -91,4 +101,4 @@ class ODConvTranspose1d(_ODConvBase):
     def forward(self, x, act=None, slope=0.1):
         att = self.kernel_attention[1]
         return Fn.odconv_transpose1d(x, self.kernels, self.bias, att.weight, att.bias, self.stride, self.padding,
-                                     self.output_padding, self.dilation, act, slope)
+                                     self.output_padding, self.dilation, act, slope, fused=self._fused())

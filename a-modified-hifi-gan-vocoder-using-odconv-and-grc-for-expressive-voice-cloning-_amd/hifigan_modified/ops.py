@@ -299,7 +299,9 @@ def conv1d_wgrad(x, gy, w, alpha, ks, stride, padding, dilation):
     nb = 1 if alpha is None else alpha.shape[1]
     gw = _f32(*((nb, Cout, Cin, ks) if alpha is not None else (Cout, Cin, ks)), device=x.device)
     galpha = torch.zeros(B, nb, device=x.device, dtype=torch.float32) if alpha is not None else None
-    N.call("mv_conv1d_wgrad", _p(x), _p(gy), _p(_c(w)) if w is not None else None, _p(alpha), _p(gw), _p(galpha),
+    wsb = N.lib().mv_conv1d_wgrad_workspace_bytes(B, Cin, Cout, ks, nb)
+    ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None
+    N.call("mv_conv1d_wgrad", _p(x), _p(gy), _p(_c(w)) if w is not None else None, _p(alpha), _p(gw), _p(galpha), _p(ws),
            B, Cin, Tin, Cout, Tout, ks, stride, padding, dilation, nb, x.stride(0), x.stride(1), gy.stride(0), gy.stride(1),
            _dt(x), _stream())
     return gw, galpha

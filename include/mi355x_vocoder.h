@@ -190,11 +190,13 @@ int mv_act_bwd(const void* gy, const void* y, void* gx, long n, int act, float s
 
 /* conv1d weight gradient (groups = 1, ks <= 16).  y = conv1d(x, w[nbanks][Cout][Cin][ks], alpha).
  *   nbanks == 1: gw [Cout][Cin][ks] = sum_{b,t} gy x ;  nbanks > 1 (ODConv): gw[k] = sum_b alpha[b,k] gW~_b and
- *   galpha[b,k] += <gW~_b, w[k]> (galpha must be zero- or bias-term-initialised by the caller; accumulated atomically).
+ *   galpha[b,k] += <gW~_b, w[k]> (galpha must be zero- or bias-term-initialised by the caller).  ODConv runs in two stages:
+ *   per-sample tiles into `workspace` (mv_conv1d_wgrad_workspace_bytes; no cross-sample atomics), then one reduction kernel.
  *   The transposed-conv weight gradient is the same call with the roles swapped (x := gy, gy := x, Cin := Cout, ...):
  *   see functional.py.  Strides as in mv_conv1d_fwd. */
+size_t mv_conv1d_wgrad_workspace_bytes(int B, int Cin, int Cout, int ks, int nbanks);
 int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, const float* alpha, float* gw, float* galpha,
-                    int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int nbanks,
+                    float* workspace, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int nbanks,
                     long x_bs, long x_cs, long g_bs, long g_cs, int dtype, void* stream);
 /* gbias[k][o] = sum_b alpha[b,k] sum_t gy[b,o,t]; galpha[b,k] += sum_o (sum_t gy[b,o,t]) bias[k][o] (K > 1).
  * rowsum_ws: fp32 [B*C] scratch. */
