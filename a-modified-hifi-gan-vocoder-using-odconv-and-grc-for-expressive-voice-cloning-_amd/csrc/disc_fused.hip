@@ -13,6 +13,7 @@
 //                    operands are read from channels-last LDS tiles with ds_read_b64_tr_b16 (hardware transpose);
 //                    position chunks are spread over workgroups and summed with fp32 atomics.
 #include "mfma.h"
+#include <cstdlib>
 
 namespace mv {
 
@@ -271,108 +272,132 @@ __global__ __launch_bounds__(256) void dhead_wgrad_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA weight gradient
-// gw[o][c][tap] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
-// workgroup = 4 waves arranged 2 (o) x 2 (c): wave (wm, wn) owns output channels o0 + 32*wm .. +31 (2 M-tiles) and input
-// channels c0 + 32*wn .. +31 (2 N-tiles) for TG consecutive taps starting at blockIdx.x % tap_groups * TG:
-// 4 transposed reads feed 4 MFMAs per tap, the accumulators of all TG taps stay in registers across the position chunks
-// the workgroup loops over, and only the final tiles are added to HBM with fp32 atomics.
-template <typename T, int TG, int TAPS_H, int TAPS_W>
-__global__ __launch_bounds__(256) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
-                                                          float* __restrict__ gw, int B, int H, int W, int Cin, int Cout,
-                                                          int WT, int wsplit, int nchunks, int chunks_per_wg, int tap_groups) {
+// gws[tap][o][c] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
+// workgroup = 8 waves arranged 2 (tap halves) x 2 (o) x 2 (c): wave (th, wm, wn) owns output channels o0 + 32*wm .. +31
+// (2 M-tiles), input channels c0 + 32*wn .. +31 (2 N-tiles) and taps th*TPW .. th*TPW+TPW-1, so one staged (g, x) chunk
+// feeds ALL taps of the 64x64 channel tile.  Chunks (WT positions of one image row + halo) are double-buffered in LDS:
+// the global loads of chunk i+1 are in flight (registers) while chunk i is multiplied.  Both operands are read with the
+// hardware-transposed ds_read_b64_tr_b16; the contraction index (position) may be permuted freely as long as A and B
+// agree, so a lane group reads rows 4*grp+q / 16+4*grp+q - with a 160-byte row stride that is bank-conflict-free.
+// Accumulators stay in registers across all chunks of the workgroup; only the final tiles go to HBM (fp32 atomics into
+// the tap-major workspace, lanes along c -> 64-byte segments), then dconv_wgrad_reorder_kernel writes [o][c][tap].
+template <typename T, int TAPS_H, int TAPS_W, int WT>
+__global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                          float* __restrict__ gws, int B, int H, int W, int Cin, int Cout,
+                                                          int wsplit, int nchunks, int chunks_per_wg) {
   static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
   using M = Mma<T>;
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  constexpr int TAPS = TAPS_H * TAPS_W;
+  constexpr int TAPS = TAPS_H * TAPS_W, TPW = (TAPS + 1) / 2;
   constexpr int PH = TAPS_H / 2, PW = TAPS_W / 2;
+  constexpr int RS = 160;                                   // 64 channels x 2 bytes + 32: conflict-free transposed reads
+  constexpr int XCOLS = WT + TAPS_W - 1;
+  constexpr int GROWS = WT, ROWS = GROWS + TAPS_H * XCOLS;
+  constexpr int BUF = ROWS * RS;
+  constexpr int NLD = (ROWS * 8 + 511) / 512;               // 16-byte pieces per thread per chunk
   extern __shared__ __align__(16) char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int th = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
   const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;   // transposed-read lane roles (guide T10)
-  const int ctile = blockIdx.x / tap_groups, tgi = blockIdx.x % tap_groups;
-  const int tap0 = tgi * TG;
-  const int o0 = blockIdx.y * 64, c0 = ctile * 64;
-  constexpr int GC = 64, XC = 64;
-  constexpr int GRS = GC * 2 + 8, XRS = XC * 2 + 8;    // row strides (bytes), multiples of 8
-  const int xcols = WT + TAPS_W - 1;
-  char* gl = lds;                                   // [WT][GC]
-  char* xl = lds + (size_t)WT * GRS;                // [TAPS_H][xcols][XC]
+  const int o0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
 
-  f32x4 acc[TG][2][2];
+  f32x4 acc[TPW][2][2];
 #pragma unroll
-  for (int t = 0; t < TG; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int n = 0; n < 2; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const char* ga = gl + (size_t)(8 * grp + q) * GRS + (wm * 32 + 4 * pp) * 2;
-  const char* xa = xl + (size_t)(8 * grp + q) * XRS + (wn * 32 + 4 * pp) * 2;
-  auto trload = [&](const char* p0, const char* p1) {
+  int toff[TPW];                                             // wave-uniform LDS offset of each tap's shifted x window
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = (th * TPW + t) < TAPS ? (th * TPW + t) : (TAPS - 1);
+    toff[t] = ((tap / TAPS_W) * XCOLS + tap % TAPS_W) * RS;
+  }
+  const int ga = (4 * grp + q) * RS + (wm * 32 + 4 * pp) * 2;
+  const int xa = GROWS * RS + (4 * grp + q) * RS + (wn * 32 + 4 * pp) * 2;
+  auto trload = [&](const char* p0) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p1);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0 + 16 * RS));
     const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     typename M::V r;
     r.v = __builtin_bit_cast(decltype(r.v), both);
     return r;
   };
 
-  for (int ci = 0; ci < chunks_per_wg; ++ci) {
-    const int chunk = blockIdx.z * chunks_per_wg + ci;
-    if (chunk >= nchunks) break;                       // uniform across the workgroup
-    const int bh = chunk / wsplit, wc = chunk % wsplit;
-    const int b = bh / H, h = bh % H;
+  u32x4 pre[NLD];
+  auto issue = [&](int chunk) {
+    const int bh = chunk / wsplit, wc = chunk - bh * wsplit;
+    const int b = bh / H, h = bh - b * H;
     const int w0 = wc * WT;
-    if (ci) __syncthreads();                           // previous chunk's reads are done before restaging
-    // stage g tile (positions w0.., channels o0..o0+63) and the x planes (rows h-PH.., cols w0-PW.., channels c0..c0+63)
-    for (int i = tid; i < WT * (GC / 8); i += 256) {
-      const int r = i / (GC / 8), ch = i % (GC / 8);
-      const int ww = w0 + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (ww < W) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(g + (((long)b * H + h) * W + ww) * Cout + o0) + ch * 16);
-      *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 16) = u32x2{v[0], v[1]};
-      *reinterpret_cast<u32x2*>(gl + (size_t)r * GRS + ch * 16 + 8) = u32x2{v[2], v[3]};
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 512;
+      const int r = idx >> 3, ch = idx & 7;
+      pre[i] = u32x4{0u, 0u, 0u, 0u};
+      if (r < GROWS) {
+        const int ww = w0 + r;
+        if (ww < W) pre[i] = *reinterpret_cast<const u32x4*>(g + (((long)b * H + h) * W + ww) * Cout + o0 + ch * 8);
+      } else if (r < ROWS) {
+        const int rr = r - GROWS;
+        const int pl = rr / XCOLS, col = rr - pl * XCOLS;
+        const int hh = h - PH + pl, ww = w0 - PW + col;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
+          pre[i] = *reinterpret_cast<const u32x4*>(x + (((long)b * H + hh) * W + ww) * Cin + c0 + ch * 8);
+      }
     }
-    for (int i = tid; i < TAPS_H * xcols * (XC / 8); i += 256) {
-      const int ch = i % (XC / 8), r = (i / (XC / 8)) % xcols, pl = i / ((XC / 8) * xcols);
-      const int hh = h - PH + pl, ww = w0 - PW + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
-        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + (((long)b * H + hh) * W + ww) * Cin + c0) + ch * 16);
-      char* dst = xl + ((size_t)pl * xcols + r) * XRS + ch * 16;
-      *reinterpret_cast<u32x2*>(dst) = u32x2{v[0], v[1]};
-      *reinterpret_cast<u32x2*>(dst + 8) = u32x2{v[2], v[3]};
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 512;
+      if (idx < ROWS * 8) *reinterpret_cast<u32x4*>(lds + buf * BUF + (idx >> 3) * RS + (idx & 7) * 16) = pre[i];
     }
-    __syncthreads();
+  };
+
+  const int cbeg = blockIdx.z * chunks_per_wg;
+  int cend = cbeg + chunks_per_wg; if (cend > nchunks) cend = nchunks;
+  if (cbeg < cend) { issue(cbeg); commit(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const bool more = chunk + 1 < cend;                 // uniform across the workgroup
+    if (more) issue(chunk + 1);
+    const char* base = lds + buf * BUF;
+#pragma unroll 1
     for (int k0 = 0; k0 < WT; k0 += 32) {
       typename M::V a[2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = trload(ga + (size_t)k0 * GRS + m * 32, ga + (size_t)(k0 + 4) * GRS + m * 32);
-      // all transposed B fragments of this position block first (independent LDS reads in flight), then the MFMAs
-      typename M::V bfr[TG][2];
+      for (int m = 0; m < 2; ++m) a[m] = trload(base + ga + k0 * RS + m * 32);
+      // a batch of transposed B fragments first (independent LDS reads in flight), then their MFMAs
+      constexpr int BT = TPW > 5 ? 4 : TPW;
 #pragma unroll
-      for (int t = 0; t < TG; ++t) {
-        const int tap = (tap0 + t) < TAPS ? (tap0 + t) : (TAPS - 1);
-        const int ih = tap / TAPS_W, iw = tap % TAPS_W;
-        const char* pb = xa + ((size_t)ih * xcols + k0 + iw) * XRS;
+      for (int tb = 0; tb < TPW; tb += BT) {
+        typename M::V bfr[BT][2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bfr[t][n] = trload(pb + n * 32, pb + 4 * XRS + n * 32);
-      }
+        for (int t = 0; t < BT; ++t)
 #pragma unroll
-      for (int t = 0; t < TG; ++t) {
-        if (tap0 + t < TAPS) {
+          for (int n = 0; n < 2; ++n)
+            if (tb + t < TPW) bfr[t][n] = trload(base + xa + toff[tb + t] + k0 * RS + n * 32);
+#pragma unroll
+        for (int t = 0; t < BT; ++t)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[t][m][n] = M::mma(a[m], bfr[t][n], acc[t][m][n]);
-        }
+            for (int m = 0; m < 2; ++m)
+              if (tb + t < TPW) acc[tb + t][m][n] = M::mma(a[m], bfr[t][n], acc[tb + t][m][n]);
       }
     }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
-  // D[row = o (4*grp + r)][col = c (li)] -> gw[o][c][tap]  (reference layout [Cout][Cin][kh][kw])
+  // D[row = o (4*grp + r)][col = c (li)] -> gws[tap][o][c]
 #pragma unroll
-  for (int t = 0; t < TG; ++t) {
-    const int tap = tap0 + t;
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = th * TPW + t;
     if (tap >= TAPS) continue;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -381,8 +406,19 @@ __global__ __launch_bounds__(256) void dconv_wgrad_kernel(const T* __restrict__ 
         const int o = o0 + wm * 32 + m * 16 + 4 * grp, c = c0 + wn * 32 + n * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (o + r < Cout && c < Cin) atomicAdd(gw + ((long)(o + r) * Cin + c) * TAPS + tap, acc[t][m][n][r]);
+          if (o + r < Cout && c < Cin) atomicAdd(gws + ((long)tap * Cout + o + r) * Cin + c, acc[t][m][n][r]);
       }
+  }
+}
+
+// gw[o][c][tap] (reference layout [Cout][Cin][kh][kw]) = gws[tap][o][c]
+__global__ __launch_bounds__(256) void dconv_wgrad_reorder_kernel(const float* __restrict__ gws, float* __restrict__ gw,
+                                                                  int OC, int taps) {
+  const long total = (long)OC * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long oc = i / taps;
+    gw[i] = gws[(long)tap * OC + oc];
   }
 }
 
@@ -614,45 +650,51 @@ extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb
   return MV_OK;
 }
 
-template <typename T, int TG, int TH, int TW_>
-static int dwgrad_launch(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
-  const int WT = 128;
+extern "C" size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int kw) {
+  return sizeof(float) * (size_t)Cin * Cout * kh * kw;
+}
+
+template <typename T, int TH, int TW_, int WT>
+static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
   const int wsplit = cdiv(W, WT);
-  const size_t lds = (size_t)WT * (64 * 2 + 8) + (size_t)TH * (WT + TW_ - 1) * (64 * 2 + 8);
+  const size_t lds = 2 * (size_t)(WT + TH * (WT + TW_ - 1)) * 160;
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = dconv_wgrad_kernel<T, TG, TH, TW_>;
-  static size_t lds_set = 0;
-  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  auto kern = dconv_wgrad_kernel<T, TH, TW_, WT>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   const long nchunks = (long)B * H * wsplit;
   if (nchunks > (1L << 30)) return MV_ERR_UNSUPPORTED;
-  const int tap_groups = cdiv(TH * TW_, TG);
-  const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64) * tap_groups;
-  // ~2048 workgroups in total: each loops over several position chunks, so the fp32 atomics at the end stay a few MB
-  int groups = 2048 / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
+  const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
+  // one workgroup per CU is resident (LDS); one round of workgroups keeps the final fp32 atomics to a few tens of MB
+  static int target = 0;
+  if (!target) { const char* e = getenv("MV_WGRAD_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+  int groups = target / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
   const int cpw = (int)((nchunks + groups - 1) / groups);
   groups = (int)((nchunks + cpw - 1) / cpw);
-  dim3 grid(cdiv(Cin, 64) * tap_groups, cdiv(Cout, 64), groups);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const T*)x, (const T*)g, gw, B, H, W, Cin, Cout, WT, wsplit,
-                     (int)nchunks, cpw, tap_groups);
+  dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), groups);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw);
   return MV_OK;
 }
 
-extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, int kh,
-                                 int kw, int dtype, void* stream) {
-  MV_CHECK_ARG(x && g && gw && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 64 == 0);
+extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin,
+                                 int Cout, int kh, int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(x && g && gw && workspace && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 64 == 0);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
   if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;   // 16-bit storage only (transposed LDS reads); callers fall back to the generic kernel
-  hipMemsetAsync(gw, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, (hipStream_t)stream);
-  int rc = MV_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, s);
+  int rc = MV_ERR_UNSUPPORTED;
   if (dtype == MV_BF16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 3, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 5, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 3, 3, 64>(x, g, workspace, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 1, 15, 128>(x, g, workspace, B, H, W, Cin, Cout, s);
   } else if (dtype == MV_F16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 3, 3, 3>(x, g, gw, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 5, 1, 15>(x, g, gw, B, H, W, Cin, Cout, s);
+    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 3, 3, 64>(x, g, workspace, B, H, W, Cin, Cout, s);
+    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 1, 15, 128>(x, g, workspace, B, H, W, Cin, Cout, s);
   }
   if (rc != MV_OK) return rc;
+  const long total = (long)Cout * Cin * kh * kw;
+  hipLaunchKernelGGL(dconv_wgrad_reorder_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),
+                     0, s, workspace, gw, Cout * Cin, kh * kw);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -158,7 +158,8 @@ class _DiscStack(Function):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             if need_w:
                 gw = f32(Cout, Cin, kh, kw)
-                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), B, H, W, Cin, Cout, kh, kw, ops._dt(g), st())
+                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(f32(kh * kw, Cout, Cin)), B, H, W, Cin, Cout, kh, kw,
+                       ops._dt(g), st())
                 gb = f32(Cout)
                 N.call("mv_colsum_cl", _P(g), _P(gb), B * H * W, Cout, ops._dt(g), st())
                 grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])

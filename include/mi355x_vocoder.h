@@ -269,7 +269,8 @@ int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr
  *   mv_dconv_cl_fwd: y = act(conv(x) + bias).  act_save (optional, [B][H][W][Cout]): data-gradient mode - the result is
  *     multiplied by LeakyReLU'(.) evaluated on that saved activation, i.e. it is d/d(pre-activation) of the previous layer.
  *   mv_dhead_*: the Cout = 1 layer (weights as fp32 [kh*kw][C] from mv_conv_out_pack-style transposition).
- *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3 and 1x15 kernels). */
+ *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3 and 1x15 kernels);
+ *     workspace: mv_dconv_wgrad_workspace_bytes() of device scratch (tap-major partial sums). */
 size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype);
 int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip, int dtype,
                   void* stream);
@@ -281,8 +282,9 @@ int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, 
                    int kw, float slope, int dtype, void* stream);
 int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
                    int dtype, void* stream);
-int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, int B, int H, int W, int Cin, int Cout, int kh, int kw,
-                      int dtype, void* stream);
+size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int kw);
+int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin, int Cout,
+                      int kh, int kw, int dtype, void* stream);
 
 /* First discriminator layer (1 -> C1 channels, LeakyReLU), channels-last output, and its gradients
  * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */
