@@ -271,6 +271,115 @@ __global__ __launch_bounds__(256) void dhead_wgrad_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ one-channel weight gradients
+// Both one-channel layers reduce a channels-last VECTOR tensor against shifted copies of a SCALAR tensor:
+//   first layer (flip = 0): gw[o][tap] = sum_pos g1[pos][o] * x0[pos + tap - pad]     vec = g1 [..][C1], sc = x0
+//   head        (flip = 1): gw[tap][c] = sum_pos x[pos][c]  * g[pos - (tap - pad)]    vec = x  [..][C],  sc = g
+// out index = c * so + tap * st.  A thread owns 8 channels (one 16-byte load per position) and all taps in registers; the
+// scalar window of the chunk sits in LDS.  Workgroups loop over row chunks, reduce across their threads through LDS and
+// add one value per (channel, tap) to HBM.  bias_mode 1: gb[c] = sum_pos vec[pos][c];  2: gb[0] = sum_pos sc[pos].
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void dtap_wgrad_kernel(const T* __restrict__ vec, const T* __restrict__ sc, float* __restrict__ gw,
+                                                         float* __restrict__ gb, int H, int W, int C, int flip, int so, int st_,
+                                                         int bias_mode, int WT, int wsplit, int nchunks, int cpw) {
+  constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+  extern __shared__ float sm[];
+  const int gwid = WT + KW - 1;
+  float* win = sm;                                  // [KH][gwid]
+  float* red = sm + KH * gwid;                      // [256][8]
+  const int tid = threadIdx.x;
+  const int tpr = C / 8, cg = tid % tpr, part = tid / tpr, nparts = 256 / tpr;
+  float acc[TAPS][8];
+  float bacc[8];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bacc[e] = 0.f;
+  float bsum = 0.f;
+  const int cbeg = blockIdx.x * cpw;
+  int cend = cbeg + cpw; if (cend > nchunks) cend = nchunks;
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const int bh = chunk / wsplit, wc = chunk - bh * wsplit;
+    const int b = bh / H, h = bh - b * H, w0 = wc * WT;
+    if (chunk > cbeg) __syncthreads();
+    for (int i = tid; i < KH * gwid; i += 256) {
+      const int ih = i / gwid, j = i - ih * gwid;
+      const int hh = flip ? h - (ih - PH) : h + (ih - PH), ww = w0 - PW + j;
+      win[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? ld<T>(sc + ((long)b * H + hh) * W + ww) : 0.f;
+    }
+    __syncthreads();
+    const int wend = (w0 + WT < W) ? w0 + WT : W;
+    const T* vrow = vec + (((long)b * H + h) * W) * C + cg * 8;
+    for (int w = w0 + part; w < wend; w += nparts) {
+      T tmp[8];
+      *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(vrow + (long)w * C);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ld<T>(tmp + e);
+      const float* wp = win + (w - w0) + (flip ? 2 * PW : 0);
+#pragma unroll
+      for (int ih = 0; ih < KH; ++ih)
+#pragma unroll
+        for (int iw = 0; iw < KW; ++iw) {
+          const float sv = flip ? wp[ih * gwid - iw] : wp[ih * gwid + iw];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[ih * KW + iw][e] += v[e] * sv;
+        }
+      if (bias_mode == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bacc[e] += v[e];
+      } else if (bias_mode == 2 && cg == 0) {
+        bsum += win[PH * gwid + (w - w0) + PW];
+      }
+    }
+  }
+  // workgroup reduction, one (tap) slice at a time; threads 0..C-1 own the final sums
+  const int myc = tid;                              // channel index for the final sum
+#pragma unroll
+  for (int t = 0; t <= TAPS; ++t) {
+    if (t == TAPS && bias_mode != 1) break;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = (t < TAPS) ? acc[t < TAPS ? t : 0][e] : bacc[e];
+    __syncthreads();
+    if (myc < C) {
+      const int g8 = myc >> 3, e = myc & 7;
+      float s = 0.f;
+      for (int q = 0; q < nparts; ++q) s += red[(q * tpr + g8) * 8 + e];
+      if (t < TAPS) atomicAdd(gw + (long)myc * so + (long)t * st_, s); else atomicAdd(gb + myc, s);
+    }
+  }
+  if (bias_mode == 2) {
+    __syncthreads();
+    const float s = block_sum(bsum, red);
+    if (tid == 0) atomicAdd(gb, s);
+  }
+}
+
+template <typename T>
+static int dtap_launch(const void* vec, const void* sc, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw, int flip,
+                       int so, int st_, int bias_mode, hipStream_t s) {
+  if (C % 8 != 0 || C > 256 || 256 % (C / 8) != 0) return MV_ERR_UNSUPPORTED;
+  const int WT = 512;
+  const int wsplit = cdiv(W, WT);
+  const long nchunks = (long)B * H * wsplit;
+  if (nchunks > (1L << 30)) return MV_ERR_UNSUPPORTED;
+  int groups = nchunks < 1024 ? (int)nchunks : 1024;
+  const int cpw = (int)((nchunks + groups - 1) / groups);
+  groups = (int)((nchunks + cpw - 1) / cpw);
+  const size_t lds = sizeof(float) * ((size_t)kh * (WT + kw - 1) + 256 * 8);
+  if (kh == 3 && kw == 3)
+    hipLaunchKernelGGL((dtap_wgrad_kernel<T, 3, 3>), dim3(groups), dim3(256), lds, s, (const T*)vec, (const T*)sc, gw, gb, H, W, C, flip,
+                       so, st_, bias_mode, WT, wsplit, (int)nchunks, cpw);
+  else if (kh == 1 && kw == 15)
+    hipLaunchKernelGGL((dtap_wgrad_kernel<T, 1, 15>), dim3(groups), dim3(256), lds, s, (const T*)vec, (const T*)sc, gw, gb, H, W, C, flip,
+                       so, st_, bias_mode, WT, wsplit, (int)nchunks, cpw);
+  else return MV_ERR_UNSUPPORTED;
+  return MV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ MFMA weight gradient
 // gws[tap][o][c] (fp32, zero on entry) += sum over this workgroup's positions of g[pos][o] * x[pos+tap][c]
 // workgroup = 8 waves arranged 2 (tap halves) x 2 (o) x 2 (c): wave (th, wm, wn) owns output channels o0 + 32*wm .. +31
@@ -641,6 +750,12 @@ extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb
   hipMemsetAsync(gw, 0, sizeof(float) * (size_t)kh * kw * C, (hipStream_t)stream);
   hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream);
   MV_CHECK_ARG(kw <= DH_MAXTAPS && H <= 65535);
+  if (dtype != MV_F32 && ((uintptr_t)x & 15) == 0) {   // 16-byte channel vectors: register-tiled reduction
+    int rc = MV_ERR_UNSUPPORTED;
+    if (dtype == MV_BF16) rc = dtap_launch<bf16>(x, g, gw, gb, B, H, W, C, kh, kw, 1, 1, C, 2, (hipStream_t)stream);
+    else if (dtype == MV_F16) rc = dtap_launch<f16>(x, g, gw, gb, B, H, W, C, kh, kw, 1, 1, C, 2, (hipStream_t)stream);
+    if (rc == MV_OK) { MV_LAUNCH_CHECK(); return MV_OK; }
+  }
   const int chunk = 256;
   dim3 grid(cdiv(W, chunk), H, B);
   const size_t lds = sizeof(float) * (size_t)kh * (chunk + kw - 1);
@@ -725,6 +840,12 @@ extern "C" int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, flo
   MV_CHECK_ARG(g1 && x0 && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0 && 256 % C1 == 0);
   hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C1 * kh * kw, (hipStream_t)stream);
   hipMemsetAsync(gb, 0, sizeof(float) * (size_t)C1, (hipStream_t)stream);
+  if (dtype != MV_F32 && ((uintptr_t)g1 & 15) == 0) {
+    int rc = MV_ERR_UNSUPPORTED;
+    if (dtype == MV_BF16) rc = dtap_launch<bf16>(g1, x0, gw, gb, B, H, W, C1, kh, kw, 0, kh * kw, 1, 1, (hipStream_t)stream);
+    else if (dtype == MV_F16) rc = dtap_launch<f16>(g1, x0, gw, gb, B, H, W, C1, kh, kw, 0, kh * kw, 1, 1, (hipStream_t)stream);
+    if (rc == MV_OK) { MV_LAUNCH_CHECK(); return MV_OK; }
+  }
   const int chunk = 1024;
   dim3 grid((unsigned)(((long)H * W + chunk - 1) / chunk), B);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g1, (const T*)x0,
