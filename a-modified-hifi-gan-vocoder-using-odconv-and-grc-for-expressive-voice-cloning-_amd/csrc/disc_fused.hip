@@ -21,6 +21,7 @@ struct DcP {
   int B, H, W, Cin, Cout, kh, kw, act;
   float slope;
   int ksteps, cin32;
+  int dil;                                        // dilation along W (1 for the discriminators; GRC convs use 1/3/5)
 };
 
 // packed[mt][kstep][lane][8]: row o = 16*mt + lane&15, k-chunk = 4*kstep + lane>>4 -> tap = chunk / (Cin/8), c = 8*(chunk % (Cin/8)) + j
@@ -28,8 +29,9 @@ struct DcP {
 // flip == 1: data-gradient weights: rows = c (previous-layer channels), k runs over (flipped tap, o)
 template <typename T, typename P>
 __global__ __launch_bounds__(256) void dconv_pack_kernel(const P* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                                         int kh, int kw, int flip) {
-  const int M = flip ? Cin : Cout, Kc = flip ? Cout : Cin;
+                                                         int kh, int kw, int flip, int Coutp, int Cinp) {
+  // w is [Cout][Cin][taps]; the packed operator is Coutp x Cinp (zero rows / columns beyond the real channel counts)
+  const int M = flip ? Cinp : Coutp, Kc = flip ? Coutp : Cinp;
   const int taps = kh * kw, cpc = Kc / 8, ksteps = taps * (Kc / 32);
   const long total = (long)(M / 16) * ksteps * 512;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -38,9 +40,9 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const P* __restrict__ w
     const int kstep = fr % ksteps, mt = fr / ksteps;
     const int row = 16 * mt + (lane & 15), chunk = 4 * kstep + (lane >> 4);
     const int tap = chunk / cpc, c = 8 * (chunk % cpc) + j;
-    float v;
-    if (!flip) v = ld<P>(w + ((long)row * Cin + c) * taps + tap);
-    else v = ld<P>(w + ((long)c * Cin + row) * taps + (taps - 1 - tap));   // w[o=c][cin=row][flipped tap]
+    float v = 0.f;
+    if (!flip) { if (row < Cout && c < Cin) v = ld<P>(w + ((long)row * Cin + c) * taps + tap); }
+    else if (c < Cout && row < Cin) v = ld<P>(w + ((long)c * Cin + row) * taps + (taps - 1 - tap));   // w[o=c][cin=row][flipped tap]
     st<T>(out + idx, v);
   }
 }
@@ -54,14 +56,14 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   constexpr int ES = M::ES;
   extern __shared__ __align__(16) char lds[];
   const int RS = lds_row_stride(p.Cin * ES, ES);
-  const int prow = NB * 16 + p.kw - 1;          // staged columns per plane
+  const int prow = NB * 16 + (p.kw - 1) * p.dil;  // staged columns per plane
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const int w0 = blockIdx.x * NB * 16;
   const int mt0 = (blockIdx.y * NWV + wid) * MW;
   const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
   const int n_mt = p.Cout / 16;
-  const int ph = p.kh / 2, pw = p.kw / 2;
+  const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
 
   // ---- stage kh input planes: rows h-ph..h+ph, columns w0-pw .. w0+NB*16+pw-1, zero outside the image
   {
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   for (int kstep = 0; kstep < p.ksteps; ++kstep) {
     if (kstep + 2 < p.ksteps) wfetch(kstep + 2, a2);
     const int ih = tap / p.kw, iw = tap % p.kw;
-    const char* bbase = lds + ((long)ih * prow + iw + col) * RS + (c32 * 32 + 8 * g) * ES;
+    const char* bbase = lds + ((long)ih * prow + iw * p.dil + col) * RS + (c32 * 32 + 8 * g) * ES;
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
       const V bf = M::load_b(bbase + (long)(n * 16) * RS);
@@ -393,18 +395,21 @@ static int dtap_launch(const void* vec, const void* sc, float* gw, float* gb, in
 template <typename T, int TAPS_H, int TAPS_W, int WT>
 __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                           float* __restrict__ gws, int B, int H, int W, int Cin, int Cout,
-                                                          int wsplit, int nchunks, int chunks_per_wg) {
+                                                          int wsplit, int nchunks, int chunks_per_wg, int dil) {
   static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
   using M = Mma<T>;
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   constexpr int TAPS = TAPS_H * TAPS_W, TPW = (TAPS + 1) / 2;
-  constexpr int PH = TAPS_H / 2, PW = TAPS_W / 2;
+  constexpr int PH = TAPS_H / 2;
   constexpr int RS = 160;                                   // 64 channels x 2 bytes + 32: conflict-free transposed reads
-  constexpr int XCOLS = WT + TAPS_W - 1;
-  constexpr int GROWS = WT, ROWS = GROWS + TAPS_H * XCOLS;
-  constexpr int BUF = ROWS * RS;
-  constexpr int NLD = (ROWS * 8 + 511) / 512;               // 16-byte pieces per thread per chunk
+  constexpr int GROWS = WT;
+  constexpr int MAXHALO = TAPS_H == 1 ? 64 : TAPS_W - 1;    // (TAPS_W - 1) * dil, checked by the launcher
+  constexpr int NLD = ((GROWS + TAPS_H * (WT + MAXHALO)) * 8 + 511) / 512;   // 16-byte pieces per thread per chunk
+  const int PW = (TAPS_W / 2) * dil;
+  const int XCOLS = WT + (TAPS_W - 1) * dil;
+  const int ROWS = GROWS + TAPS_H * XCOLS;
+  const int BUF = ROWS * RS;
   extern __shared__ __align__(16) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tap = (th * TPW + t) < TAPS ? (th * TPW + t) : (TAPS - 1);
-    toff[t] = ((tap / TAPS_W) * XCOLS + tap % TAPS_W) * RS;
+    toff[t] = ((tap / TAPS_W) * XCOLS + (tap % TAPS_W) * dil) * RS;
   }
   const int ga = (4 * grp + q) * RS + (wm * 32 + 4 * pp) * 2;
   const int xa = GROWS * RS + (4 * grp + q) * RS + (wn * 32 + 4 * pp) * 2;
@@ -448,10 +453,10 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
       pre[i] = u32x4{0u, 0u, 0u, 0u};
       if (r < GROWS) {
         const int ww = w0 + r;
-        if (ww < W) pre[i] = *reinterpret_cast<const u32x4*>(g + (((long)b * H + h) * W + ww) * Cout + o0 + ch * 8);
+        if (ww < W && o0 + ch * 8 < Cout) pre[i] = *reinterpret_cast<const u32x4*>(g + (((long)b * H + h) * W + ww) * Cout + o0 + ch * 8);
       } else if (r < ROWS) {
         const int rr = r - GROWS;
-        const int pl = rr / XCOLS, col = rr - pl * XCOLS;
+        const int pl = TAPS_H == 1 ? 0 : rr / XCOLS, col = rr - pl * XCOLS;
         const int hh = h - PH + pl, ww = w0 - PW + col;
         if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
           pre[i] = *reinterpret_cast<const u32x4*>(x + (((long)b * H + hh) * W + ww) * Cin + c0 + ch * 8);
@@ -662,18 +667,18 @@ extern "C" size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int d
   return (size_t)Cout * Cin * kh * kw * (dtype == MV_F32 ? 4 : 2);
 }
 
-extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip,
-                             int dtype, void* stream) {
-  MV_CHECK_ARG(w && packed && Cout % 16 == 0 && Cin % 32 == 0 && kh > 0 && kw > 0);
-  const int Mr = flip ? Cin : Cout, Kc = flip ? Cout : Cin;
+extern "C" int mv_dconv_pack_pad(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int Coutp,
+                                 int Cinp, int flip, int dtype, void* stream) {
+  MV_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && Coutp >= Cout && Cinp >= Cin && kh > 0 && kw > 0);
+  const int Mr = flip ? Cinp : Coutp, Kc = flip ? Coutp : Cinp;
   MV_CHECK_ARG(Mr % 16 == 0 && Kc % 32 == 0);
-  const long total = (long)Cout * Cin * kh * kw;
+  const long total = (long)Coutp * Cinp * kh * kw;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   MV_DISPATCH(dtype, {
     switch (param_dtype) {
-      case MV_F32: hipLaunchKernelGGL((dconv_pack_kernel<T, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
-      case MV_BF16: hipLaunchKernelGGL((dconv_pack_kernel<T, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
-      case MV_F16: hipLaunchKernelGGL((dconv_pack_kernel<T, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)w, (T*)packed, Cout, Cin, kh, kw, flip); break;
+      case MV_F32: hipLaunchKernelGGL((dconv_pack_kernel<T, float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)w, (T*)packed, Cout, Cin, kh, kw, flip, Coutp, Cinp); break;
+      case MV_BF16: hipLaunchKernelGGL((dconv_pack_kernel<T, bf16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, (T*)packed, Cout, Cin, kh, kw, flip, Coutp, Cinp); break;
+      case MV_F16: hipLaunchKernelGGL((dconv_pack_kernel<T, f16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)w, (T*)packed, Cout, Cin, kh, kw, flip, Coutp, Cinp); break;
       default: return MV_ERR_DTYPE;
     }
   });
@@ -681,10 +686,16 @@ extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int C
   return MV_OK;
 }
 
+extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip,
+                             int dtype, void* stream) {
+  MV_CHECK_ARG(Cout % 16 == 0 && Cin % 32 == 0);
+  return mv_dconv_pack_pad(w, param_dtype, packed, Cout, Cin, kh, kw, Cout, Cin, flip, dtype, stream);
+}
+
 template <typename T, int NWV, int MW, int NB>
 static int dconv_launch(const void* x, const void* wp, const void* bias, const void* actsave, void* y, DcP p, hipStream_t s) {
   using M = Mma<T>;
-  const int prow = NB * 16 + p.kw - 1;
+  const int prow = NB * 16 + (p.kw - 1) * p.dil;
   const size_t xb = (size_t)p.kh * prow * lds_row_stride(p.Cin * M::ES, M::ES);
   const size_t ob = (size_t)NB * 16 * (NWV * MW * 16 * M::ES + 16);
   const size_t lds = xb > ob ? xb : ob;
@@ -699,11 +710,12 @@ static int dconv_launch(const void* x, const void* wp, const void* bias, const v
 }
 
 extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y,
-                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int act, float slope, int dtype,
+                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype,
                                void* stream) {
   MV_CHECK_ARG(x && packed && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 16 == 0 && (kh & 1) && (kw & 1));
+  MV_CHECK_ARG(dil_w >= 1 && (kw - 1) * dil_w <= 128);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0 && Cout % 8 == 0);
-  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32};
+  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w};
   int rc = MV_ERR_DTYPE;
   MV_DISPATCH(dtype, {
     hipStream_t s_ = (hipStream_t)stream;
@@ -770,13 +782,15 @@ extern "C" size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int 
 }
 
 template <typename T, int TH, int TW_, int WT>
-static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H, int W, int Cin, int Cout, int dil, hipStream_t s) {
   const int wsplit = cdiv(W, WT);
-  const size_t lds = 2 * (size_t)(WT + TH * (WT + TW_ - 1)) * 160;
+  const int halo = (TW_ - 1) * dil;
+  if (halo > (TH == 1 ? 64 : TW_ - 1)) return MV_ERR_UNSUPPORTED;
+  const size_t lds = 2 * (size_t)(WT + TH * (WT + halo)) * 160;
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
   auto kern = dconv_wgrad_kernel<T, TH, TW_, WT>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  static size_t lds_set = 0;
+  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   const long nchunks = (long)B * H * wsplit;
   if (nchunks > (1L << 30)) return MV_ERR_UNSUPPORTED;
   const int tiles = cdiv(Cin, 64) * cdiv(Cout, 64);
@@ -787,25 +801,36 @@ static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H,
   const int cpw = (int)((nchunks + groups - 1) / groups);
   groups = (int)((nchunks + cpw - 1) / cpw);
   dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), groups);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw, dil);
   return MV_OK;
 }
 
+template <typename T>
+static int dwgrad_dispatch(const void* x, const void* g, float* ws, int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil,
+                           hipStream_t s) {
+  if (kh == 3 && kw == 3) return dil == 1 ? dwgrad_launch<T, 3, 3, 64>(x, g, ws, B, H, W, Cin, Cout, 1, s) : MV_ERR_UNSUPPORTED;
+  if (kh != 1) return MV_ERR_UNSUPPORTED;
+  switch (kw) {
+    case 1: return dwgrad_launch<T, 1, 1, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 3: return dwgrad_launch<T, 1, 3, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 5: return dwgrad_launch<T, 1, 5, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 7: return dwgrad_launch<T, 1, 7, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 11: return dwgrad_launch<T, 1, 11, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 15: return dwgrad_launch<T, 1, 15, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    default: return MV_ERR_UNSUPPORTED;
+  }
+}
+
 extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin,
-                                 int Cout, int kh, int kw, int dtype, void* stream) {
-  MV_CHECK_ARG(x && g && gw && workspace && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 64 == 0);
+                                 int Cout, int kh, int kw, int dil_w, int dtype, void* stream) {
+  MV_CHECK_ARG(x && g && gw && workspace && B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && dil_w >= 1);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
   if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;   // 16-bit storage only (transposed LDS reads); callers fall back to the generic kernel
   hipStream_t s = (hipStream_t)stream;
   hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, s);
   int rc = MV_ERR_UNSUPPORTED;
-  if (dtype == MV_BF16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<bf16, 3, 3, 64>(x, g, workspace, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<bf16, 1, 15, 128>(x, g, workspace, B, H, W, Cin, Cout, s);
-  } else if (dtype == MV_F16) {
-    if (kh == 3 && kw == 3) rc = dwgrad_launch<f16, 3, 3, 64>(x, g, workspace, B, H, W, Cin, Cout, s);
-    else if (kh == 1 && kw == 15) rc = dwgrad_launch<f16, 1, 15, 128>(x, g, workspace, B, H, W, Cin, Cout, s);
-  }
+  if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, B, H, W, Cin, Cout, kh, kw, dil_w, s);
+  else if (dtype == MV_F16) rc = dwgrad_dispatch<f16>(x, g, workspace, B, H, W, Cin, Cout, kh, kw, dil_w, s);
   if (rc != MV_OK) return rc;
   const long total = (long)Cout * Cin * kh * kw;
   hipLaunchKernelGGL(dconv_wgrad_reorder_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),

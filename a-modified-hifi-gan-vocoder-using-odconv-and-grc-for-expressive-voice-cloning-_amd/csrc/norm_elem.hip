@@ -161,17 +161,17 @@ __global__ __launch_bounds__(256) void mpd_fold_kernel(const T* __restrict__ x, 
 
 // ---------------------------------------------------------------- layout transposes (32x32 LDS tiles)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn) {
-  // x [batch][R][Cn] -> y [batch][Cn][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn, int ldx, int ldy) {
+  // x [batch][R][ldx] (columns < Cn used) -> y [batch][Cn][ldy]; y columns R..ldy-1 are zero-filled (channel padding)
   __shared__ float tile[32][33];
-  const long base = (long)blockIdx.z * R * Cn;
+  const long bx = (long)blockIdx.z * R * ldx, by = (long)blockIdx.z * Cn * ldy;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8)
-    if (r0 + i < R && c0 + tx < Cn) tile[i][tx] = ld<T>(x + base + (long)(r0 + i) * Cn + c0 + tx);
+    tile[i][tx] = (r0 + i < R && c0 + tx < Cn) ? ld<T>(x + bx + (long)(r0 + i) * ldx + c0 + tx) : 0.f;
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
-    if (c0 + i < Cn && r0 + tx < R) st<T>(y + base + (long)(c0 + i) * R + r0 + tx, tile[tx][i]);
+    if (c0 + i < Cn && r0 + tx < ldy) st<T>(y + by + (long)(c0 + i) * ldy + r0 + tx, tile[tx][i]);
 }
 
 template <typename S, typename D>
@@ -324,19 +324,27 @@ extern "C" int mv_mpd_fold(const void* x, void* y, int64_t* index, long rows, in
   return MV_OK;
 }
 
-static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, int dtype, void* stream) {
-  MV_CHECK_ARG(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0 && cdiv(R, 32) <= 65535);
-  dim3 grid(cdiv(Cn, 32), cdiv(R, 32), batch);
+static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, int ldx, int ldy, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0 && ldx >= Cn && ldy >= R && cdiv(ldy, 32) <= 65535);
+  dim3 grid(cdiv(Cn, 32), cdiv(ldy, 32), batch);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
-                                        (T*)y, R, Cn));
+                                        (T*)y, R, Cn, ldx, ldy));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
 extern "C" int mv_nct_to_ntc(const void* x, void* y, int B, int C, int T_, int dtype, void* stream) {
-  return transpose_launch(x, y, B, C, T_, dtype, stream);
+  return transpose_launch(x, y, B, C, T_, T_, C, dtype, stream);
 }
 extern "C" int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T_, int dtype, void* stream) {
-  return transpose_launch(x, y, B, T_, C, dtype, stream);
+  return transpose_launch(x, y, B, T_, C, C, T_, dtype, stream);
+}
+extern "C" int mv_nct_to_ntc_pad(const void* x, void* y, int B, int C, int T_, int Cpad, int dtype, void* stream) {
+  MV_CHECK_ARG(Cpad >= C);
+  return transpose_launch(x, y, B, C, T_, T_, Cpad, dtype, stream);
+}
+extern "C" int mv_ntc_to_nct_crop(const void* x, void* y, int B, int C, int T_, int Cpad, int dtype, void* stream) {
+  MV_CHECK_ARG(Cpad >= C);
+  return transpose_launch(x, y, B, T_, C, Cpad, T_, dtype, stream);
 }
 
 template <typename S>

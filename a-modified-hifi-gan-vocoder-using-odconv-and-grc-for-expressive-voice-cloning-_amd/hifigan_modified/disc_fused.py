@@ -111,14 +111,14 @@ class _DiscStack(Function):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             y = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
             N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(params[2 * li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
-                   kh, kw, N.ACT_LRELU, float(slope), ops._dt(x0), st())
+                   kh, kw, 1, N.ACT_LRELU, float(slope), ops._dt(x0), st())
             acts.append(y)
         C4 = ws[4].shape[1]
         out = torch.empty((B, 1, H, W) if x0.dim() == 4 else (B, 1, W), device=dev, dtype=dt)
         # head (C4 -> 1) on the MFMA conv with the output zero-padded to 32 channels, then channel 0 is extracted
         hp, hb = _packs.head_padded(params[8], bs[4], dt, 0)
         y32 = torch.empty(B, H, W, 32, device=dev, dtype=dt)
-        N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(hp), _P(hb), None, _P(y32), B, H, W, C4, 32, kh, kw, N.ACT_NONE, float(slope),
+        N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(hp), _P(hb), None, _P(y32), B, H, W, C4, 32, kh, kw, 1, N.ACT_NONE, float(slope),
                ops._dt(x0), st())
         N.call("mv_take_channel", _P(y32), _P(out), B * H * W, 32, 0, ops._dt(x0), st())
         ctx.geom = (B, H, W, kh, kw, float(slope), x0.dim())
@@ -151,21 +151,21 @@ class _DiscStack(Function):
         N.call("mv_put_channel", _P(gy), _P(g32), B * H * W, 32, 0, ops._dt(gy), st())
         g = torch.empty(B, H, W, C4, device=dev, dtype=dt)
         hpf, _ = _packs.head_padded(params[8], bs[4], dt, 1)
-        N.call("mv_dconv_cl_fwd", _P(g32), _P(hpf), None, _P(acts[3]), _P(g), B, H, W, 32, C4, kh, kw, N.ACT_NONE, slope,
+        N.call("mv_dconv_cl_fwd", _P(g32), _P(hpf), None, _P(acts[3]), _P(g), B, H, W, 32, C4, kh, kw, 1, N.ACT_NONE, slope,
                ops._dt(gy), st())
         # ---- wide layers 4, 3, 2 (indices 3, 2, 1)
         for li in (3, 2, 1):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             if need_w:
                 gw = f32(Cout, Cin, kh, kw)
-                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(f32(kh * kw, Cout, Cin)), B, H, W, Cin, Cout, kh, kw,
+                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(f32(kh * kw, Cout, Cin)), B, H, W, Cin, Cout, kh, kw, 1,
                        ops._dt(g), st())
                 gb = f32(Cout)
                 N.call("mv_colsum_cl", _P(g), _P(gb), B * H * W, Cout, ops._dt(g), st())
                 grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])
             gprev = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
             N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(params[2 * li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,
-                   kh, kw, N.ACT_NONE, slope, ops._dt(g), st())
+                   kh, kw, 1, N.ACT_NONE, slope, ops._dt(g), st())
             g = gprev
         # ---- first layer
         C1 = ws[0].shape[0]

@@ -119,14 +119,30 @@ def odconv_transpose1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, outp
 
 # ----------------------------------------------------------------------------------------------- plain convolutions
 class _Conv1d(Function):
-    """nn.Conv1d (+ fused activation).  cfg = (stride, padding, dilation, groups, act, slope)."""
+    """nn.Conv1d (+ fused activation).  cfg = (stride, padding, dilation, groups, act, slope).
+    16-bit dense stride-1 'same' convs (the GRC / fusion convs of grc_lora.py:36-41,148) run forward, data gradient and
+    weight gradient on the channels-last MFMA kernels; everything else on the generic NCT kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
         stride, padding, dilation, groups, act, slope = cfg
         x = x if x.stride(2) == 1 else x.contiguous()
-        y = ops.conv1d(x, _w(weight, x), _w(bias, x), None, stride, padding, dilation, groups, act, slope)
         ctx.cfg = cfg
+        ctx.mfma = act == N.ACT_NONE and ops.mfma_conv1d_ok(x, weight, stride, padding, dilation, groups)
+        if ctx.mfma:
+            Cout, Cin, ks = weight.shape
+            cop, cip = ops._up32(Cout), ops._up32(Cin)
+            x_cl = ops.nct_to_ntc(x, cip)
+            bp = None
+            if bias is not None:
+                bp = _w(bias, x)
+                if cop != Cout:                       # parameter-sized glue: bias zero-padded to the MFMA granule
+                    bp = torch.zeros(cop, device=x.device, dtype=x.dtype)
+                    bp[:Cout] = _w(bias, x)
+            y_cl = ops.dconv_cl(x_cl, ops.dconv_pack(weight.reshape(Cout, Cin, 1, ks), x.dtype, 0, cop, cip), bp, cop, 1, ks, dilation)
+            ctx.save_for_backward(x_cl, weight, bias, None)
+            return ops.ntc_to_nct(y_cl, Cout)
+        y = ops.conv1d(x, _w(weight, x), _w(bias, x), None, stride, padding, dilation, groups, act, slope)
         ctx.save_for_backward(x, weight, bias, y if act != N.ACT_NONE else None)
         return y
 
@@ -134,6 +150,26 @@ class _Conv1d(Function):
     def backward(ctx, gy):
         x, weight, bias, y = ctx.saved_tensors
         stride, padding, dilation, groups, act, slope = ctx.cfg
+        if ctx.mfma:
+            Cout, Cin, ks = weight.shape
+            cop, cip = ops._up32(Cout), ops._up32(Cin)
+            gy = gy if gy.is_contiguous() else gy.contiguous()
+            g_cl = ops.nct_to_ntc(gy, cop)
+            gx = gw = gb = None
+            if ctx.needs_input_grad[0]:
+                gx_cl = ops.dconv_cl(g_cl, ops.dconv_pack(weight.reshape(Cout, Cin, 1, ks), gy.dtype, 1, cop, cip), None, cip, 1, ks,
+                                     dilation)
+                gx = ops.ntc_to_nct(gx_cl, Cin)
+            if ctx.needs_input_grad[1]:
+                gwp = ops.dconv_wgrad_cl(x, g_cl, 1, ks, dilation).view(cop, cip, ks)
+                if (cop, cip) != (Cout, Cin):
+                    gwc = torch.empty(Cout, Cin, ks, device=gwp.device, dtype=gwp.dtype)
+                    ops.copy_rows(gwp.view(1, cop, cip * ks)[:, :Cout], gwc.view(1, Cout, Cin * ks))
+                    gwp = gwc
+                gw = _to(gwp, weight)
+            if bias is not None and ctx.needs_input_grad[2]:
+                gb = _to(ops.bias_grad(gy), bias)
+            return gx, gw, gb, None
         if groups != 1:
             raise NotImplementedError("mi355x vocoder: backward of grouped conv1d is not available in this build")
         gy = gy if gy.is_contiguous() else gy.contiguous()

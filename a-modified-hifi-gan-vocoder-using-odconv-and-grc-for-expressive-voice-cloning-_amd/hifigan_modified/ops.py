@@ -261,27 +261,94 @@ def mpd_fold(x, period, want_index=False):
     return (y, index.view(period, Tp // period)) if want_index else y
 
 
-def nct_to_ntc(x):
+def nct_to_ntc(x, cpad=None):
+    """[B,C,T] -> channels-last [B,T,C] (or [B,T,cpad] with zero channels C..cpad-1)."""
     _need_gpu(x)
     x = _c(x)
     B, C, T = x.shape
-    y = torch.empty(B, T, C, device=x.device, dtype=x.dtype)
-    N.call("mv_nct_to_ntc", _p(x), _p(y), B, C, T, _dt(x), _stream())
+    if cpad is None or cpad == C:
+        y = torch.empty(B, T, C, device=x.device, dtype=x.dtype)
+        N.call("mv_nct_to_ntc", _p(x), _p(y), B, C, T, _dt(x), _stream())
+    else:
+        y = torch.empty(B, T, cpad, device=x.device, dtype=x.dtype)
+        N.call("mv_nct_to_ntc_pad", _p(x), _p(y), B, C, T, cpad, _dt(x), _stream())
     return y
 
 
-def ntc_to_nct(x):
+def ntc_to_nct(x, c=None):
+    """channels-last [B,T,Cp] -> [B,C,T] (first C channels when c is given)."""
     _need_gpu(x)
     x = _c(x)
-    B, T, C = x.shape
-    y = torch.empty(B, C, T, device=x.device, dtype=x.dtype)
-    N.call("mv_ntc_to_nct", _p(x), _p(y), B, C, T, _dt(x), _stream())
+    B, T, Cp = x.shape
+    if c is None or c == Cp:
+        y = torch.empty(B, Cp, T, device=x.device, dtype=x.dtype)
+        N.call("mv_ntc_to_nct", _p(x), _p(y), B, Cp, T, _dt(x), _stream())
+    else:
+        y = torch.empty(B, c, T, device=x.device, dtype=x.dtype)
+        N.call("mv_ntc_to_nct_crop", _p(x), _p(y), B, c, T, Cp, _dt(x), _stream())
     return y
 
 
 # ------------------------------------------------------------------------------------------------ backward / training ops
 def _f32(*shape, device):
     return torch.empty(*shape, device=device, dtype=torch.float32)
+
+# ----------------------------------------------------------------------------------------------- channels-last MFMA convs
+_MFMA_KS = (1, 3, 5, 7, 11, 15)
+
+
+def _up32(c):
+    return (c + 31) // 32 * 32
+
+
+def mfma_conv1d_ok(x, weight, stride, padding, dilation, groups) -> bool:
+    """True when a Conv1d can run on the channels-last MFMA kernels (csrc/disc_fused.hip): 16-bit storage, stride 1,
+    'same' padding, dense.  Channel counts are zero-padded to the 32-channel MFMA granule."""
+    if x.dtype not in (torch.bfloat16, torch.float16) or not x.is_cuda:
+        return False
+    Cout, Cin, ks = weight.shape
+    return (groups == 1 and stride == 1 and ks in _MFMA_KS and padding == dilation * (ks - 1) // 2
+            and (ks - 1) * dilation <= 64 and Cin >= 16 and Cout >= 16)
+
+
+def dconv_pack(w4, dtype, flip, coutp=None, cinp=None):
+    """[Cout,Cin,kh,kw] weights -> MFMA A-fragment order (flip=1: the data-gradient operator), zero-padded to
+    coutp x cinp channels."""
+    Cout, Cin, kh, kw = w4.shape
+    coutp, cinp = coutp or Cout, cinp or Cin
+    w4 = w4.detach().contiguous()
+    buf = torch.empty(N.lib().mv_dconv_packed_bytes(coutp, cinp, kh, kw, _DT[dtype]), dtype=torch.uint8, device=w4.device)
+    N.call("mv_dconv_pack_pad", _p(w4), _DT[w4.dtype], _p(buf), Cout, Cin, kh, kw, coutp, cinp, int(flip), _DT[dtype], _stream())
+    return buf
+
+
+def dconv_cl(x_cl, packed, bias, Cout, kh, kw, dil=1, act=N.ACT_NONE, slope=0.1, act_save=None):
+    """x_cl [B,H,W,Cin] (or [B,W,Cin]) channels-last -> [.., Cout]."""
+    shp = x_cl.shape
+    B, H, W, Cin = (shp[0], 1, shp[1], shp[2]) if x_cl.dim() == 3 else shp
+    y = torch.empty(*shp[:-1], Cout, device=x_cl.device, dtype=x_cl.dtype)
+    N.call("mv_dconv_cl_fwd", _p(x_cl), _p(packed), _p(bias), _p(act_save), _p(y), B, H, W, Cin, Cout, kh, kw, dil, act, float(slope),
+           _dt(x_cl), _stream())
+    return y
+
+
+def dconv_wgrad_cl(x_cl, g_cl, kh, kw, dil=1):
+    """fp32 [Cout,Cin,kh,kw] = sum_pos g x (transposed-LDS-read MFMA GEMM)."""
+    shp = x_cl.shape
+    B, H, W, Cin = (shp[0], 1, shp[1], shp[2]) if x_cl.dim() == 3 else shp
+    Cout = g_cl.shape[-1]
+    gw = _f32(Cout, Cin, kh, kw, device=x_cl.device)
+    ws = _f32(kh * kw, Cout, Cin, device=x_cl.device)
+    N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
+    return gw
+
+
+def colsum_cl(g_cl):
+    C = g_cl.shape[-1]
+    out = _f32(C, device=g_cl.device)
+    N.call("mv_colsum_cl", _p(g_cl), _p(out), g_cl.numel() // C, C, _dt(g_cl), _stream())
+    return out
+
 
 
 def act_bwd(gy, y, kind, slope=0.1):

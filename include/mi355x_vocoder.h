@@ -119,6 +119,11 @@ int mv_mpd_fold(const void* x, void* y, int64_t* index, long rows, int T, int P,
 /* Layout transposes between the public NCT layout and the private channels-last NTC layout. */
 int mv_nct_to_ntc(const void* x, void* y, int B, int C, int T, int dtype, void* stream);
 int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T, int dtype, void* stream);
+/* Same transposes with the channel axis zero-padded to / cropped from Cpad on the channels-last side
+ * (x [B][C][T] -> y [B][T][Cpad] with zeros in channels C..Cpad-1; x [B][T][Cpad] -> y [B][C][T]): the GRC branch widths
+ * (20 and 60 channels, grc_lora.py:86-93) are padded to the 32-channel MFMA granule this way. */
+int mv_nct_to_ntc_pad(const void* x, void* y, int B, int C, int T, int Cpad, int dtype, void* stream);
+int mv_ntc_to_nct_crop(const void* x, void* y, int B, int C, int T, int Cpad, int dtype, void* stream);
 
 /* dtype conversion (fp32 <-> bf16/fp16) of n elements. */
 int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream);
@@ -269,13 +274,17 @@ int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr
  *   mv_dconv_cl_fwd: y = act(conv(x) + bias).  act_save (optional, [B][H][W][Cout]): data-gradient mode - the result is
  *     multiplied by LeakyReLU'(.) evaluated on that saved activation, i.e. it is d/d(pre-activation) of the previous layer.
  *   mv_dhead_*: the Cout = 1 layer (weights as fp32 [kh*kw][C] from mv_conv_out_pack-style transposition).
- *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3 and 1x15 kernels);
+ *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3, and 1xk for k in 1,3,5,7,11,15
+ *     with W-dilation dil_w, (k-1)*dil_w <= 64 - the GRC/MRF convs of grc_lora.py:36-41 run through the same kernels);
  *     workspace: mv_dconv_wgrad_workspace_bytes() of device scratch (tap-major partial sums). */
 size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype);
 int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip, int dtype,
                   void* stream);
+/* mv_dconv_pack with the operator zero-padded to Coutp x Cinp channels (multiples of 32 for the side that is contracted). */
+int mv_dconv_pack_pad(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int Coutp, int Cinp,
+                      int flip, int dtype, void* stream);
 int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y, int B, int H,
-                    int W, int Cin, int Cout, int kh, int kw, int act, float slope, int dtype, void* stream);
+                    int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype, void* stream);
 int mv_dhead_fwd(const void* x, const float* wt, float bias, void* y, int B, int H, int W, int C, int kh, int kw,
                  int dtype, void* stream);
 int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
@@ -284,7 +293,7 @@ int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, in
                    int dtype, void* stream);
 size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int kw);
 int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin, int Cout,
-                      int kh, int kw, int dtype, void* stream);
+                      int kh, int kw, int dil_w, int dtype, void* stream);
 
 /* First discriminator layer (1 -> C1 channels, LeakyReLU), channels-last output, and its gradients
  * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */

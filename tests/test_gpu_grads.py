@@ -268,3 +268,32 @@ def test_disc_fused_mfma_vs_fp32(H, dtype, kind, arg, T, slope):
         fwd_tol, g_tol = (3e-3, 1e-1) if dtype == torch.float16 else (2e-2, 2.5e-1)   # kink-flip noise varies with atomics order
     assert errs["y"] < fwd_tol, errs
     assert all(v < g_tol for k, v in errs.items() if k != "y"), {k: f"{v:.1e}" for k, v in errs.items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,cout,ks,dil,T", [(64, 64, 3, 1, 1000), (64, 64, 7, 3, 777), (64, 64, 11, 5, 1024), (192, 64, 1, 1, 300),
+                                               (32, 128, 5, 2, 130), (64, 256, 15, 1, 515), (64, 20, 3, 3, 900), (64, 20, 3, 5, 257), (60, 64, 1, 1, 640)])
+def test_conv1d_mfma_route_vs_fp64(H, dtype, cin, cout, ks, dil, T):
+    """16-bit dense 'same' Conv1d (the GRC / fusion convs, grc_lora.py:36-41,148) on the channels-last MFMA kernels:
+    forward, data gradient, weight gradient (transposed-LDS-read GEMM with W-dilation) and bias gradient against an fp64
+    torch-CPU conv on the same 16-bit-rounded inputs.  The op is linear, so only rounding remains."""
+    import torch.nn.functional as F
+    from hifigan_modified import functional as Fn, ops
+    torch.manual_seed(0)
+    B = 3
+    x = torch.randn(B, cin, T).to(dtype)
+    w = (torch.randn(cout, cin, ks) / (cin * ks) ** 0.5).to(dtype)
+    b = torch.randn(cout).to(dtype)
+    r = torch.randn(B, cout, T).to(dtype)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv1d(xr, wr, br, padding=dil * (ks - 1) // 2, dilation=dil)
+    (yr * r.double()).sum().backward()
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    assert ops.mfma_conv1d_ok(xd, wd, 1, dil * (ks - 1) // 2, dil, 1)
+    y = Fn.conv1d(xd, wd, bd, padding=dil * (ks - 1) // 2, dilation=dil)
+    (y.float() * r.cuda().float()).sum().backward()
+    eps = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    assert O.rel_l2(y.detach().cpu(), yr.detach()) < eps
+    assert O.rel_l2(xd.grad.cpu(), xr.grad) < eps
+    assert O.rel_l2(wd.grad.cpu(), wr.grad) < eps
+    assert O.rel_l2(bd.grad.cpu(), br.grad) < eps
