@@ -170,59 +170,132 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ 256 -> 1 head
-// forward: y[pos] = b + sum_{tap,c} w[tap][c] x[pos+tap][c]     (wt fp32 [taps][C])
-template <typename T>
-__global__ __launch_bounds__(256) void dhead_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wt, float bias,
-                                                        T* __restrict__ y, int H, int W, int C, int kh, int kw) {
-  // one wave per output position: lanes split the channels (C/64 each), taps looped
-  const int lane = threadIdx.x & 63;
-  const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long total = (long)gridDim.y * 0 + 0; (void)total;
-  const int b = blockIdx.y;
-  if (pos >= (long)H * W) return;
-  const int h = (int)(pos / W), w = (int)(pos % W);
-  const int ph = kh / 2, pw = kw / 2;
-  float acc = 0.f;
-  for (int ih = 0; ih < kh; ++ih) {
-    const int hh = h + ih - ph;
-    if (hh < 0 || hh >= H) continue;
-    for (int iw = 0; iw < kw; ++iw) {
-      const int ww = w + iw - pw;
-      if (ww < 0 || ww >= W) continue;
-      const T* xr = x + (((long)b * H + hh) * W + ww) * C;
-      const float* wr = wt + (ih * kw + iw) * C;
-      for (int c = lane; c < C; c += 64) acc += ld<T>(xr + c) * wr[c];
+// The head has ONE output channel, so the MFMA rows carry the TAPS instead:
+//   forward   z[tap][pos] = sum_c w[c][tap] x[pos][c]      (a 1x1 "conv" with 16 output rows = taps, K = C; x read once,
+//             straight from HBM as the B operand - no shifted windows), then  y[pos] = b + sum_tap z[tap][pos + off(tap)]
+//   dgrad     gx[pos][c]  = lrelu'(save[pos][c]) * sum_tap w[c][tap] gy[pos - off(tap)]   (rows = channels, K = taps <= 32:
+//             one MFMA per 16 channels x 16 positions; rows are permuted so a lane owns C/4 CONTIGUOUS channels)
+// Both are HBM-bound: x / gx / save are touched exactly once.
+constexpr int DH_C = 256;                           // head input width of both discriminator families
+
+// packed forward operator [C/32][lane][8]: row = tap (lane&15), k = 32*ks + 8*(lane>>4) + j = channel
+// packed dgrad operator   [C/16][lane][8]: m-tile mt, row i = lane&15 -> channel (i>>2)*(C/4) + 4*mt + (i&3); k = tap
+template <typename T, typename P>
+__global__ __launch_bounds__(256) void dhead_pack_kernel(const P* __restrict__ w, T* __restrict__ pf, T* __restrict__ pd, int C, int taps) {
+  const int nf = (C / 32) * 512, nd = (C / 16) * 512;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nf + nd; idx += gridDim.x * blockDim.x) {
+    if (idx < nf) {
+      const int j = idx % 8, lane = (idx / 8) % 64, ks = idx / 512;
+      const int tap = lane & 15, c = 32 * ks + 8 * (lane >> 4) + j;
+      st<T>(pf + idx, tap < taps ? ld<P>(w + (long)c * taps + tap) : 0.f);
+    } else {
+      const int i2 = idx - nf;
+      const int j = i2 % 8, lane = (i2 / 8) % 64, mt = i2 / 512;
+      const int i = lane & 15, c = (i >> 2) * (C / 4) + 4 * mt + (i & 3), tap = 8 * (lane >> 4) + j;
+      st<T>(pd + i2, tap < taps ? ld<P>(w + (long)c * taps + tap) : 0.f);
     }
   }
-  acc = wave_sum(acc);
-  if (lane == 0) st<T>(y + (long)b * H * W + pos, acc + bias);
 }
 
-// data gradient of the head, fused with LeakyReLU' of the previous layer:
-// gx[pos][c] = lrelu'(xsave[pos][c]) * sum_tap w[tap][c] g[pos - tap]
 template <typename T>
-__global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ g, const float* __restrict__ wt,
-                                                          const T* __restrict__ xsave, T* __restrict__ gx, int H, int W,
-                                                          int C, int kh, int kw, float slope) {
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void dhead_z_kernel(const T* __restrict__ x, const T* __restrict__ pf, float* __restrict__ z,
+                                                      long npos, int taps) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int KS = DH_C / 32;
+  const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  V a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = M::load_b(reinterpret_cast<const char*>(pf) + ((long)ks * 64 + lane) * 16);
+  const long ngroups = (npos + 15) / 16;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  for (long grp = wave; grp < ngroups; grp += nwaves) {
+    const long pos = grp * 16 + col;
+    const long pc = pos < npos ? pos : npos - 1;
+    const char* xr = reinterpret_cast<const char*>(x + pc * DH_C) + g * 16;
+    V bfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bfr[ks] = M::load_b(xr + ks * 64);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = M::mma(a[ks], bfr[ks], acc);
+    if (pos < npos) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < taps) z[(long)(4 * g + r) * npos + pos] = acc[r];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dhead_sum_kernel(const float* __restrict__ z, const T* __restrict__ bias, T* __restrict__ y,
+                                                        int B, int H, int W, int kh, int kw) {
+  const long npos = (long)B * H * W;
   const int ph = kh / 2, pw = kw / 2;
-  const long npos = (long)H * W;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npos * C; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const long pos = i / C;
-    const int h = (int)(pos / W), w = (int)(pos % W);
-    float acc = 0.f;
+  const float bv = bias ? ld<T>(bias) : 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npos; i += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W), h = (int)((i / W) % H);
+    float acc = bv;
     for (int ih = 0; ih < kh; ++ih) {
-      const int hh = h - (ih - ph);
+      const int hh = h + ih - ph;
       if (hh < 0 || hh >= H) continue;
       for (int iw = 0; iw < kw; ++iw) {
-        const int ww = w - (iw - pw);
+        const int ww = w + iw - pw;
         if (ww < 0 || ww >= W) continue;
-        acc += wt[(ih * kw + iw) * C + c] * ld<T>(g + (long)b * npos + (long)hh * W + ww);
+        acc += z[(long)(ih * kw + iw) * npos + i + (long)(ih - ph) * W + (iw - pw)];
       }
     }
-    const float s = ld<T>(xsave + ((long)b * npos + pos) * C + c);
-    st<T>(gx + ((long)b * npos + pos) * C + c, s >= 0.f ? acc : acc * slope);
+    st<T>(y + i, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ gy, const T* __restrict__ pd, const T* __restrict__ save,
+                                                          T* __restrict__ gx, int B, int H, int W, int kh, int kw, float slope) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int NMT = DH_C / 16;
+  const long npos = (long)B * H * W;
+  const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
+  const int ph = kh / 2, pw = kw / 2, taps = kh * kw;
+  const long ngroups = (npos + 15) / 16;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const char* pa = reinterpret_cast<const char*>(pd) + (long)lane * 16;
+  for (long grp = wave; grp < ngroups; grp += nwaves) {
+    const long pos = grp * 16 + col;
+    const bool ok = pos < npos;
+    const long pc = ok ? pos : npos - 1;
+    const int w = (int)(pc % W), h = (int)((pc / W) % H);
+    // B[k = tap = 8g + j][col]: gy at the position this tap reaches (gy is tiny and cache-resident)
+    alignas(16) T bt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 8 * g + j;
+      const int ih = tap / kw, iw = tap - ih * kw;
+      const int hh = h - (ih - ph), ww = w - (iw - pw);
+      float v = 0.f;
+      if (tap < taps && hh >= 0 && hh < H && ww >= 0 && ww < W) v = ld<T>(gy + pc - (long)(ih - ph) * W - (iw - pw));
+      st<T>(bt + j, v);
+    }
+    const V bfr = M::load_b(bt);
+    // this lane's C/4 contiguous channels: g*(C/4) + 4*mt + r
+    const T* srow = save + pc * DH_C + g * (DH_C / 4);
+    T* orow = gx + pc * DH_C + g * (DH_C / 4);
+#pragma unroll
+    for (int m2 = 0; m2 < NMT; m2 += 2) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 d0 = M::mma(M::load_b(pa + (long)m2 * 1024), bfr, zero);
+      const f32x4 d1 = M::mma(M::load_b(pa + (long)(m2 + 1) * 1024), bfr, zero);
+      alignas(16) T sv[8];
+      alignas(16) T ov[8];
+      *reinterpret_cast<u32x4*>(sv) = *reinterpret_cast<const u32x4*>(srow + 4 * m2);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        st<T>(ov + r, ld<T>(sv + r) >= 0.f ? d0[r] : d0[r] * slope);
+        st<T>(ov + 4 + r, ld<T>(sv + 4 + r) >= 0.f ? d1[r] : d1[r] * slope);
+      }
+      if (ok) *reinterpret_cast<u32x4*>(orow + 4 * m2) = *reinterpret_cast<u32x4*>(ov);
+    }
   }
 }
 
@@ -735,23 +808,59 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   return MV_OK;
 }
 
-extern "C" int mv_dhead_fwd(const void* x, const float* wt, float bias, void* y, int B, int H, int W, int C, int kh, int kw,
-                            int dtype, void* stream) {
-  MV_CHECK_ARG(x && wt && y && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0);
-  dim3 grid((unsigned)(((long)H * W + 3) / 4), B);
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, wt, bias,
-                                        (T*)y, H, W, C, kh, kw));
+extern "C" size_t mv_dhead_packed_bytes(int C, int dtype) { return (size_t)(C / 32 + C / 16) * 512 * (dtype == MV_F32 ? 4 : 2); }
+extern "C" size_t mv_dhead_workspace_bytes(int B, int H, int W) { return sizeof(float) * 16 * (size_t)B * H * W; }
+
+extern "C" int mv_dhead_pack(const void* w, int param_dtype, void* packed, int C, int kh, int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(w && packed && C == DH_C && kh * kw <= 16);
+  if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;
+  MV_DISPATCH(dtype, {
+    T* pf = (T*)packed; T* pd = pf + (C / 32) * 512;
+    switch (param_dtype) {
+      case MV_F32: hipLaunchKernelGGL((dhead_pack_kernel<T, float>), dim3(24), dim3(256), 0, (hipStream_t)stream, (const float*)w, pf, pd, C, kh * kw); break;
+      case MV_BF16: hipLaunchKernelGGL((dhead_pack_kernel<T, bf16>), dim3(24), dim3(256), 0, (hipStream_t)stream, (const bf16*)w, pf, pd, C, kh * kw); break;
+      case MV_F16: hipLaunchKernelGGL((dhead_pack_kernel<T, f16>), dim3(24), dim3(256), 0, (hipStream_t)stream, (const f16*)w, pf, pd, C, kh * kw); break;
+      default: return MV_ERR_DTYPE;
+    }
+  });
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
 
-extern "C" int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
+template <typename T>
+static void dhead_fwd_launch(const void* x, const void* packed, const void* bias, float* ws, void* y, int B, int H, int W, int kh,
+                             int kw, hipStream_t s) {
+  const long npos = (long)B * H * W;
+  const long groups = (npos + 15) / 16;
+  const int grid = (int)((groups + 3) / 4 > 4096 ? 4096 : (groups + 3) / 4);
+  hipLaunchKernelGGL(dhead_z_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)packed, ws, npos, kh * kw);
+  hipLaunchKernelGGL(dhead_sum_kernel<T>, dim3((unsigned)((npos + 255) / 256 > 4096 ? 4096 : (npos + 255) / 256)), dim3(256), 0, s,
+                     ws, (const T*)bias, (T*)y, B, H, W, kh, kw);
+}
+
+extern "C" int mv_dhead_fwd(const void* x, const void* packed, const void* bias, float* workspace, void* y, int B, int H, int W,
+                            int C, int kh, int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(x && packed && workspace && y && B > 0 && H > 0 && W > 0 && C == DH_C && kh * kw <= 16 && ((uintptr_t)x & 15) == 0);
+  if (dtype == MV_BF16) dhead_fwd_launch<bf16>(x, packed, bias, workspace, y, B, H, W, kh, kw, (hipStream_t)stream);
+  else if (dtype == MV_F16) dhead_fwd_launch<f16>(x, packed, bias, workspace, y, B, H, W, kh, kw, (hipStream_t)stream);
+  else return MV_ERR_UNSUPPORTED;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dhead_dgrad(const void* g, const void* packed, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
                               int kw, float slope, int dtype, void* stream) {
-  MV_CHECK_ARG(g && wt && xsave && gx && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0);
-  const long n = (long)H * W * C;
-  dim3 grid((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256), B);
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(dhead_dgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, wt,
-                                        (const T*)xsave, (T*)gx, H, W, C, kh, kw, slope));
+  MV_CHECK_ARG(g && packed && xsave && gx && B > 0 && H > 0 && W > 0 && C == DH_C && kh * kw <= 16);
+  MV_CHECK_ARG(((uintptr_t)xsave & 15) == 0 && ((uintptr_t)gx & 15) == 0);
+  const long groups = ((long)B * H * W + 15) / 16;
+  const int grid = (int)((groups + 3) / 4 > 4096 ? 4096 : (groups + 3) / 4);
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL(dhead_dgrad_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)g,
+                       (const bf16*)packed + (C / 32) * 512, (const bf16*)xsave, (bf16*)gx, B, H, W, kh, kw, slope);
+  else if (dtype == MV_F16)
+    hipLaunchKernelGGL(dhead_dgrad_kernel<f16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)g,
+                       (const f16*)packed + (C / 32) * 512, (const f16*)xsave, (f16*)gx, B, H, W, kh, kw, slope);
+  else return MV_ERR_UNSUPPORTED;
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -69,6 +69,18 @@ class _PackCache:
         bias[0:1] = bparam.detach().to(dtype)
         return self._store(key, wparam, ver, (buf, bias))
 
+    def head_mfma(self, param, dtype):
+        """[1,C,kh,kw] head -> the tap-row MFMA operators of mv_dhead_fwd / mv_dhead_dgrad."""
+        key, ver, buf = self._lookup(param, ("headmfma", dtype))
+        if buf is not None:
+            return buf
+        w = _as4d(param)
+        C, kh, kw = w.shape[1], w.shape[2], w.shape[3]
+        buf = torch.empty(N.lib().mv_dhead_packed_bytes(C, ops._DT[dtype]), dtype=torch.uint8, device=w.device)
+        wd = w.detach().contiguous()
+        N.call("mv_dhead_pack", _P(wd), ops._DT[wd.dtype], _P(buf), C, kh, kw, ops._DT[dtype], ops._stream())
+        return self._store(key, param, ver, buf)
+
     def head(self, param):
         """[1,C,kh,kw] (or [1,C,k]) -> fp32 [taps][C]."""
         key, ver, buf = self._lookup(param, "head")
@@ -115,12 +127,18 @@ class _DiscStack(Function):
             acts.append(y)
         C4 = ws[4].shape[1]
         out = torch.empty((B, 1, H, W) if x0.dim() == 4 else (B, 1, W), device=dev, dtype=dt)
-        # head (C4 -> 1) on the MFMA conv with the output zero-padded to 32 channels, then channel 0 is extracted
-        hp, hb = _packs.head_padded(params[8], bs[4], dt, 0)
-        y32 = torch.empty(B, H, W, 32, device=dev, dtype=dt)
-        N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(hp), _P(hb), None, _P(y32), B, H, W, C4, 32, kh, kw, 1, N.ACT_NONE, float(slope),
-               ops._dt(x0), st())
-        N.call("mv_take_channel", _P(y32), _P(out), B * H * W, 32, 0, ops._dt(x0), st())
+        if C4 == 256 and kh * kw <= 16:
+            # head (C4 -> 1): taps on the MFMA rows, x read once (mv_dhead_fwd)
+            zws = torch.empty(16, B * H * W, device=dev, dtype=torch.float32)
+            N.call("mv_dhead_fwd", _P(acts[-1]), _P(_packs.head_mfma(params[8], dt)), _P(cast(bs[4])), _P(zws), _P(out), B, H, W, C4,
+                   kh, kw, ops._dt(x0), st())
+        else:
+            # generic width: MFMA conv with the output zero-padded to 32 channels, then channel 0 is extracted
+            hp, hb = _packs.head_padded(params[8], bs[4], dt, 0)
+            y32 = torch.empty(B, H, W, 32, device=dev, dtype=dt)
+            N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(hp), _P(hb), None, _P(y32), B, H, W, C4, 32, kh, kw, 1, N.ACT_NONE, float(slope),
+                   ops._dt(x0), st())
+            N.call("mv_take_channel", _P(y32), _P(out), B * H * W, 32, 0, ops._dt(x0), st())
         ctx.geom = (B, H, W, kh, kw, float(slope), x0.dim())
         ctx.save_for_backward(x0, *acts, *params)
         return out
@@ -147,12 +165,16 @@ class _DiscStack(Function):
             gw5 = f32(C4, kh * kw)                       # [taps][C] -> [C][taps] with our own transpose kernel
             N.call("mv_ntc_to_nct", _P(gwt), _P(gw5), 1, C4, kh * kw, N.MV_F32, st())
             grads[8], grads[9] = to(gw5, params[8]), to(gb5, params[9])
-        g32 = torch.empty(B, H, W, 32, device=dev, dtype=dt)
-        N.call("mv_put_channel", _P(gy), _P(g32), B * H * W, 32, 0, ops._dt(gy), st())
         g = torch.empty(B, H, W, C4, device=dev, dtype=dt)
-        hpf, _ = _packs.head_padded(params[8], bs[4], dt, 1)
-        N.call("mv_dconv_cl_fwd", _P(g32), _P(hpf), None, _P(acts[3]), _P(g), B, H, W, 32, C4, kh, kw, 1, N.ACT_NONE, slope,
-               ops._dt(gy), st())
+        if C4 == 256 and kh * kw <= 16:
+            N.call("mv_dhead_dgrad", _P(gy), _P(_packs.head_mfma(params[8], dt)), _P(acts[3]), _P(g), B, H, W, C4, kh, kw, slope,
+                   ops._dt(gy), st())
+        else:
+            g32 = torch.empty(B, H, W, 32, device=dev, dtype=dt)
+            N.call("mv_put_channel", _P(gy), _P(g32), B * H * W, 32, 0, ops._dt(gy), st())
+            hpf, _ = _packs.head_padded(params[8], bs[4], dt, 1)
+            N.call("mv_dconv_cl_fwd", _P(g32), _P(hpf), None, _P(acts[3]), _P(g), B, H, W, 32, C4, kh, kw, 1, N.ACT_NONE, slope,
+                   ops._dt(gy), st())
         # ---- wide layers 4, 3, 2 (indices 3, 2, 1)
         for li in (3, 2, 1):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]

@@ -285,9 +285,16 @@ int mv_dconv_pack_pad(const void* w, int param_dtype, void* packed, int Cout, in
                       int flip, int dtype, void* stream);
 int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y, int B, int H,
                     int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype, void* stream);
-int mv_dhead_fwd(const void* x, const float* wt, float bias, void* y, int B, int H, int W, int C, int kh, int kw,
-                 int dtype, void* stream);
-int mv_dhead_dgrad(const void* g, const float* wt, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
+/* Head (C = 256 -> 1 channel, discriminators.py:65 / :106) on MFMA with the taps on the matrix rows; 16-bit storage.
+ *   mv_dhead_pack: w [1][C][kh][kw] -> forward + data-gradient operators (mv_dhead_packed_bytes).
+ *   mv_dhead_fwd:  y [B][H][W] = bias[0] + conv(x [B][H][W][C]); workspace: mv_dhead_workspace_bytes (per-tap partial sums).
+ *   mv_dhead_dgrad: gx [B][H][W][C] = LeakyReLU'(xsave) * conv^T(g [B][H][W]). */
+size_t mv_dhead_packed_bytes(int C, int dtype);
+size_t mv_dhead_workspace_bytes(int B, int H, int W);
+int mv_dhead_pack(const void* w, int param_dtype, void* packed, int C, int kh, int kw, int dtype, void* stream);
+int mv_dhead_fwd(const void* x, const void* packed, const void* bias, float* workspace, void* y, int B, int H, int W, int C,
+                 int kh, int kw, int dtype, void* stream);
+int mv_dhead_dgrad(const void* g, const void* packed, const void* xsave, void* gx, int B, int H, int W, int C, int kh,
                    int kw, float slope, int dtype, void* stream);
 int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
                    int dtype, void* stream);
