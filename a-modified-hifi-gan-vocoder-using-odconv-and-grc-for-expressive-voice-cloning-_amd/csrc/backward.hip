@@ -454,7 +454,7 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
                        (const T*)w, alpha, dst, galpha, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, nbanks, x_bs, x_cs,
                        g_bs, g_cs, tsplit, tchunk, per_sample);
     if (per_sample) {
-      const int epb = 4096;
+      const int epb = 256;       // one element per thread: the B x K wave reductions of a block stay short
       hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
                          sizeof(float) * B * nbanks, (hipStream_t)stream, workspace, (const T*)w, alpha, gw, galpha, B,
                          nbanks, nelem, epb);

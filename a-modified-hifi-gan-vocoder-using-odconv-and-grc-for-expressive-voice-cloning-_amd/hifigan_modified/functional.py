@@ -83,12 +83,15 @@ class _ODConv(Function):
         ks = kernels.shape[3]
         B, Cin, Tin = x.shape
         Tout = g.shape[2]
-        # data gradient: the adjoint convolution with the same (alpha-aggregated) kernels
-        if transposed:
-            gx = ops.conv1d(g, wk, None, alpha, stride, padding, dilation, 1)
-        else:
-            opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)
-            gx = ops.conv_transpose1d(g, wk, None, alpha, stride, padding, opad, dilation)
+        # data gradient: the adjoint convolution with the same (alpha-aggregated) kernels (skipped for a leaf input
+        # such as the mel batch, whose gradient nobody consumes)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if transposed:
+                gx = ops.conv1d(g, wk, None, alpha, stride, padding, dilation, 1)
+            else:
+                opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)
+                gx = ops.conv_transpose1d(g, wk, None, alpha, stride, padding, opad, dilation)
         # kernel-bank gradient + d alpha = <per-sample wgrad, W_k>
         if transposed:   # same kernel with the roles of input and output-gradient swapped
             gw, galpha = ops.conv1d_wgrad(g, x, wk, alpha, ks, stride, padding, dilation)
@@ -96,7 +99,8 @@ class _ODConv(Function):
             gw, galpha = ops.conv1d_wgrad(x, g, wk, alpha, ks, stride, padding, dilation)
         gb = ops.bias_grad(g, alpha, _w(bias, x), galpha)
         gwa, gba, gm = ops.odconv_attn_bwd(alpha, galpha, pooled, _w(att_w, x).view(K, C), Tin)
-        ops.add_rowconst_(gx, gm)          # the pooling path: (1/T) Wa^T gz added to every time step
+        if gx is not None:
+            ops.add_rowconst_(gx, gm)      # the pooling path: (1/T) Wa^T gz added to every time step
         return gx, _to(gw, kernels), _to(gb, bias), _to(gwa, att_w), _to(gba, att_b), None, None
 
 
