@@ -20,6 +20,7 @@
 // staged once per workgroup.
 #include "mfma.h"
 #include <cstring>
+#include <cstdio>
 
 namespace mv {
 
@@ -153,9 +154,32 @@ __global__ __launch_bounds__(256) void mrf_pack_kernel(MrfRawParams p, MrfMeta m
 }
 
 // ------------------------------------------------------------------------------------------------ forward passes
+// The reference's (and the default generator's) dilations are (1, 3, 5): for that case the tap table is a compile-time
+// constant, so stage 1 becomes straight-line code that the kernel software-pipelines (operands of k-step s+1 are read
+// from LDS while the MFMAs of k-step s run).  Any other dilation set takes the table from MrfMeta at run time.
+__host__ __device__ constexpr int mrf_std_off(int tap) { return tap == 0 ? -5 : tap == 1 ? -3 : tap == 2 ? -1 : tap == 3 ? 0 : tap == 4 ? 1 : tap == 5 ? 3 : 5; }
+__host__ __device__ constexpr int mrf_std_frag(int m, int tap) {
+  // mrf_make_meta's numbering for dil = {1,3,5}: M-tile 0 uses taps 2,3,4; 1: 1..5; 2: 0,1,3,5,6; 3: 0,3,6
+  return m == 0 ? (tap >= 2 && tap <= 4 ? tap - 2 : -1)
+       : m == 1 ? (tap >= 1 && tap <= 5 ? 3 + tap - 1 : -1)
+       : m == 2 ? (tap == 0 ? 8 : tap == 1 ? 9 : tap == 3 ? 10 : tap == 5 ? 11 : tap == 6 ? 12 : -1)
+                : (tap == 0 ? 13 : tap == 3 ? 14 : tap == 6 ? 15 : -1);
+}
+static inline bool mrf_meta_is_std(const MrfMeta& m) {
+  if (m.ntaps != 7 || m.halo != 5) return false;
+  for (int t = 0; t < 7; ++t) {
+    if (m.tap_off[t] != mrf_std_off(t)) return false;
+    for (int a = 0; a < 4; ++a) if (m.frag_of[a][t] != mrf_std_frag(a, t)) return false;
+  }
+  return true;
+}
+
 constexpr int MRF_HMAX = 8;   // largest dilation the fused kernel accepts (prefetch registers are sized for it)
 
-template <typename T, int NWAVES, int NTW, int PASS>
+#ifdef MV_MRF_TIMING
+__device__ long long* mrf_dbg = nullptr;
+#endif
+template <typename T, int NWAVES, int NTW, int PASS, bool STD>
 __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ x, T* __restrict__ out,
                                                           const char* __restrict__ packed, MrfMeta meta,
                                                           const float* __restrict__ part5, float* __restrict__ part5_out,
@@ -184,6 +208,13 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   const int col = lane & 15, g = lane >> 4;
   const int b = blockIdx.y, wg = blockIdx.x;
   const int H = meta.halo;
+#ifdef MV_MRF_TIMING
+  long long tmk[12]; int ntm = 0;
+#define MRF_TM() do { if (ntm < 12) tmk[ntm++] = clock64(); } while (0)
+  MRF_TM();
+#else
+#define MRF_TM() do {} while (0)
+#endif
   const int rows = TW + 2 * H;
   char* xw = xl + (size_t)wid * rows * RS;
   const T* xb = x + (size_t)b * Tn * MRF_C;
@@ -214,19 +245,48 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   };
   issue(0);
 
-  // ---- stage packed weights + tables (whole workgroup, once)
+  // ---- stage packed weights + tables (whole workgroup, once): all global loads of a thread in flight together
   {
-    const int n16 = (WBYTES + MRF_TAB_FLOATS * 4) / 16;
+    constexpr int N16 = (WBYTES + MRF_TAB_FLOATS * 4) / 16;
+    constexpr int PER = (N16 + NWAVES * 64 - 1) / (NWAVES * 64);
     const u32x4* src = reinterpret_cast<const u32x4*>(packed);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
-    for (int i = tid; i < n16; i += NWAVES * 64) dst[i] = src[i];
+    u32x4 wv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * NWAVES * 64;
+      wv[i] = src[idx < N16 ? idx : N16 - 1];
+    }
+    // GroupNorm statistics from the previous passes' partial sums: one partial per thread, then a fixed-order sum in LDS
+    float2 pp = {0.f, 0.f};
+    const int pi = tid >> 4, pq = tid & 15;                 // (workgroup index, group) for GN5; GN8 uses threads 256..
+    if (PASS >= 2 && pi < nwg && tid < 256) pp = *reinterpret_cast<const float2*>(part5 + ((size_t)(b * nwg + pi) * 16 + pq) * 2);
+    float2 pp8 = {0.f, 0.f};
+    const int t8 = tid - 256, pi8 = t8 >> 3, pq8 = t8 & 7;
+    if (PASS >= 3 && NWAVES * 64 >= 512 && t8 >= 0 && pi8 < nwg && t8 < 128) pp8 = *reinterpret_cast<const float2*>(part8 + ((size_t)(b * nwg + pi8) * 8 + pq8) * 2);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = tid + i * NWAVES * 64;
+      if (idx < N16) dst[idx] = wv[i];
+    }
+    // xl (the waves' x tiles) is not written before the first commit(): use its head as scratch for the partials
+    float2* sc5 = reinterpret_cast<float2*>(xl);
+    float2* sc8 = sc5 + 256;
+    if (PASS >= 2 && tid < 256) sc5[tid] = pp;
+    if (PASS >= 3 && NWAVES * 64 >= 512 && t8 >= 0 && t8 < 128) sc8[t8] = pp8;
   }
-  // ---- GroupNorm statistics from the previous passes' partial sums (fixed summation order)
+  const bool fast_stats = nwg <= 16 && NWAVES * 64 >= 512;
+  if (PASS >= 2) __syncthreads();
   if (PASS >= 2 && tid < 16) {
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < nwg; ++i) {
-      s1 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2];
-      s2 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2 + 1];
+    if (fast_stats) {
+      const float2* sc5 = reinterpret_cast<const float2*>(xl);
+      for (int i = 0; i < nwg; ++i) { s1 += sc5[i * 16 + tid].x; s2 += sc5[i * 16 + tid].y; }
+    } else {
+      for (int i = 0; i < nwg; ++i) {
+        s1 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2];
+        s2 += part5[((size_t)(b * nwg + i) * 16 + tid) * 2 + 1];
+      }
     }
     const float n = 4.f * (float)Tn, mu = s1 / n;
     const float var = fmaxf(s2 / n - mu * mu, 0.f);
@@ -236,9 +296,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   if (PASS >= 3 && tid >= 64 && tid < 72) {
     const int q = tid - 64;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < nwg; ++i) {
-      s1 += part8[((size_t)(b * nwg + i) * 8 + q) * 2];
-      s2 += part8[((size_t)(b * nwg + i) * 8 + q) * 2 + 1];
+    if (fast_stats) {
+      const float2* sc8 = reinterpret_cast<const float2*>(xl) + 256;
+      for (int i = 0; i < nwg; ++i) { s1 += sc8[i * 8 + q].x; s2 += sc8[i * 8 + q].y; }
+    } else {
+      for (int i = 0; i < nwg; ++i) {
+        s1 += part8[((size_t)(b * nwg + i) * 8 + q) * 2];
+        s2 += part8[((size_t)(b * nwg + i) * 8 + q) * 2 + 1];
+      }
     }
     const float n = 8.f * (float)Tn, mu = s1 / n;
     const float var = fmaxf(s2 / n - mu * mu, 0.f);
@@ -246,6 +311,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     st8[q * 2 + 1] = rsqrtf(var + eps);
   }
   __syncthreads();
+  MRF_TM();
 
   const float* b_conv = tab, *b_res = tab + 64, *b_fus = tab + 128;
   const float* g5 = tab + 192, *be5 = tab + 256, *g8 = tab + 320, *be8 = tab + 384;
@@ -257,6 +323,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   for (int it = 0; it < nit; ++it) {
     const int t0 = tile_t0(it);
     commit();                       // this tile: registers -> this wave's private LDS region
+    MRF_TM();
     if (it + 1 < nit) issue(it + 1);
     __builtin_amdgcn_wave_barrier();
 
@@ -268,6 +335,30 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
       for (int n = 0; n < NTW; ++n) v[m][n] = bi;
     }
+    if (STD) {
+      // straight-line, software-pipelined: step s = (tap, ks); two operand sets alternate
+      V bfr[2][NTW], afr[2][4];
+      auto ld_step = [&](int sidx, int set) {
+        const int tap = sidx >> 1, ks = sidx & 1;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) bfr[set][n] = M::load_b(xcol + (n * 16 + mrf_std_off(tap)) * RS + ks * 32 * ES);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (mrf_std_frag(m, tap) >= 0) afr[set][m] = M::load_a(wl + (size_t)(mrf_std_frag(m, tap) * 2 + ks) * FS + lane * 16, FRAG_BYTES);
+      };
+      ld_step(0, 0);
+#pragma unroll
+      for (int sidx = 0; sidx < 14; ++sidx) {
+        if (sidx + 1 < 14) ld_step(sidx + 1, (sidx + 1) & 1);
+        const int tap = sidx >> 1, set = sidx & 1;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (mrf_std_frag(m, tap) >= 0) {
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(afr[set][m], bfr[set][n], v[m][n]);
+          }
+      }
+    } else
     for (int tap = 0; tap < meta.ntaps; ++tap) {
       const int off = meta.tap_off[tap];
 #pragma unroll
@@ -291,6 +382,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       }
     }
 
+    MRF_TM();
     if (PASS == 1) {
       // partial sums of v per GN(5,20) group: concat rows 16m+4g..+3 are exactly group 4m+g
 #pragma unroll
@@ -357,6 +449,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
         for (int n = 0; n < NTW; ++n) f[m][n] = M::mma(af[m], cb[n], f[m][n]);
     }
 
+    MRF_TM();
     if (PASS == 2) {
       // partial sums of f per GN(8,64) group: rows 16m+4g+r -> group 2m + (g>>1)
 #pragma unroll
@@ -404,7 +497,15 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       if (t < Tn) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + ch * 16) = val;
     }
     __builtin_amdgcn_wave_barrier();
+    MRF_TM();
   }
+#ifdef MV_MRF_TIMING
+  MRF_TM();
+  if (lane == 0 && mrf_dbg) {
+    long long* d = mrf_dbg + ((size_t)(PASS - 1) * 65536 + ((size_t)(b * nwg + wg) * NWAVES + wid)) * 12;
+    for (int i = 0; i < 12; ++i) d[i] = i < ntm ? tmk[i] - tmk[0] : -1;
+  }
+#endif
 
   if (PASS == 1) {
 #pragma unroll
@@ -465,15 +566,21 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
   float* part5 = ws;
   float* part8 = ws + (size_t)B * nwg * 32;
   dim3 grid(nwg, B), block(NWAVES * 64);
-  auto k1 = mrf_kernel<T, NWAVES, NTW, 1>;
-  auto k2 = mrf_kernel<T, NWAVES, NTW, 2>;
-  auto k3 = mrf_kernel<T, NWAVES, NTW, 3>;
-  static size_t lds_set = 0;   // per instantiation: raise the dynamic-LDS limit once (and again if a larger halo needs it)
-  if (lds > lds_set) {
+#ifdef MV_MRF_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 3 * 65536 * 12 * 8); hipMemset(dbg, 0xff, 3 * 65536 * 12 * 8); hipMemcpyToSymbol(HIP_SYMBOL(mrf_dbg), &dbg, sizeof(dbg)); }
+#endif
+  const bool stdm = mrf_meta_is_std(meta);
+  auto k1 = stdm ? mrf_kernel<T, NWAVES, NTW, 1, true> : mrf_kernel<T, NWAVES, NTW, 1, false>;
+  auto k2 = stdm ? mrf_kernel<T, NWAVES, NTW, 2, true> : mrf_kernel<T, NWAVES, NTW, 2, false>;
+  auto k3 = stdm ? mrf_kernel<T, NWAVES, NTW, 3, true> : mrf_kernel<T, NWAVES, NTW, 3, false>;
+  static size_t lds_set[2] = {0, 0};   // per instantiation: raise the dynamic-LDS limit once (and again if a larger halo needs it)
+  if (lds > lds_set[stdm]) {
     (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_set = lds;
+    lds_set[stdm] = lds;
   }
   hipLaunchKernelGGL(k1, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, nullptr, part5,
                      nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps);
@@ -481,6 +588,21 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
                      nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps);
   hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
                      part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps);
+#ifdef MV_MRF_TIMING
+  if (++calls == 40) {
+    hipStreamSynchronize(stream);
+    static long long hbuf[3 * 65536 * 12];
+    hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+    const int nwv = B * nwg * NWAVES;
+    for (int ps = 0; ps < 3; ++ps) {
+      double avg[12] = {0}; int cnt[12] = {0};
+      for (int w = 0; w < nwv; ++w) for (int i = 0; i < 12; ++i) { long long v = hbuf[((size_t)ps * 65536 + w) * 12 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
+      fprintf(stderr, "[mrf timing] pass %d (nwg %d nit %d) clock64 marks:", ps + 1, nwg, nit);
+      for (int i = 0; i < 12; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return MV_OK;
 }
 
