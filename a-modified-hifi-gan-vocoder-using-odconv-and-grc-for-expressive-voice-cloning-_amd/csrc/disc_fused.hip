@@ -65,18 +65,33 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   const int n_mt = p.Cout / 16;
   const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
 
-  // ---- stage kh input planes: rows h-ph..h+ph, columns w0-pw .. w0+NB*16+pw-1, zero outside the image
+  // ---- stage kh input planes: rows h-ph..h+ph, columns w0-pw .. w0+NB*16+pw-1, zero outside the image.
+  //      UB global loads per thread are in flight together (a load -> wait -> LDS-store loop costs one full memory
+  //      latency per 16 bytes and dominated the 3x3 layers)
   {
-    const int cpr = p.Cin * ES / 16;
-    const int per = prow * cpr;
-    for (int i = tid; i < p.kh * per; i += NWV * 64) {
-      const int pl = i / per, rem = i % per;
-      const int r = rem / cpr, ch = rem % cpr;
-      const int hh = h - ph + pl, ww = w0 - pw + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + (((long)b * p.H + hh) * p.W + ww) * p.Cin) + ch * 16);
-      *reinterpret_cast<u32x4*>(lds + ((long)pl * prow + r) * RS + ch * 16) = v;
+    constexpr int UB = 8;
+    const int cpr = p.Cin * ES / 16;             // 16-byte pieces per row; a thread keeps its piece and walks rows
+    const int rpp = (NWV * 64) / cpr;            // rows covered by one sweep of the workgroup (threads beyond rpp*cpr idle)
+    const int ch = tid % cpr;
+    const int nrow = tid < rpp * cpr ? p.kh * prow : 0;
+    const char* xb = reinterpret_cast<const char*>(x + (long)b * p.H * p.W * p.Cin) + ch * 16;
+    for (int R0 = tid / cpr; R0 < nrow; R0 += rpp * UB) {
+      u32x4 v[UB];
+      int dsto[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int R = R0 + u * rpp;
+        int pl = 0, r = R;
+        while (r >= prow) { r -= prow; ++pl; }   // kh <= 3 planes
+        const int hh = h - ph + pl, ww = w0 - pw + r;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        dsto[u] = R < nrow ? R * RS + ch * 16 : -1;
+        if (R < nrow && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+          v[u] = *reinterpret_cast<const u32x4*>(xb + ((long)hh * p.W + ww) * p.Cin * ES);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (dsto[u] >= 0) *reinterpret_cast<u32x4*>(lds + dsto[u]) = v[u];
     }
   }
   __syncthreads();
@@ -773,6 +788,8 @@ static int dconv_launch(const void* x, const void* wp, const void* bias, const v
   const size_t ob = (size_t)NB * 16 * (NWV * MW * 16 * M::ES + 16);
   const size_t lds = xb > ob ? xb : ob;
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  const int cpr = p.Cin * M::ES / 16;
+  if (cpr > NWV * 64) return MV_ERR_UNSUPPORTED;   // staging: a thread keeps its 16-byte piece of every row it copies
   auto kern = dconv_cl_kernel<T, NWV, MW, NB>;
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
