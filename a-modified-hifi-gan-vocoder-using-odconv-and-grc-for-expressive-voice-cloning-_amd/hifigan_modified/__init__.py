@@ -11,10 +11,13 @@ from .complete_vocoder import ModifiedHiFiGANVocoder, VocoderTrainer
 from .conditioned_hifigan import ConditionedHiFiGAN, HiFiGANTrainer
 from .discriminators import (HiFiGANDiscriminators, MultiPeriodDiscriminator, MultiScaleDiscriminator,
                              Discriminator1D, Discriminator2D)
+from .streaming import ChunkedVocoder
+from .data import MelFrontEnd, ClipSampler
 
 __all__ = [
     "ODConv1d", "ODConvTranspose1d", "GRC_LoRA_Block", "FiLMLayer", "MultiReceptiveFieldBlock",
     "ModifiedHiFiGANGenerator", "HiFiGANGenerator", "GroupedResidualConv1D", "FeatureWiseLinearModulation",
     "HiFiGANDiscriminators", "MultiPeriodDiscriminator", "MultiScaleDiscriminator", "Discriminator1D",
     "Discriminator2D", "ModifiedHiFiGANVocoder", "VocoderTrainer", "ConditionedHiFiGAN", "HiFiGANTrainer",
+    "ChunkedVocoder", "MelFrontEnd", "ClipSampler",
 ]
