@@ -13,11 +13,12 @@ from .discriminators import (HiFiGANDiscriminators, MultiPeriodDiscriminator, Mu
                              Discriminator1D, Discriminator2D)
 from .streaming import ChunkedVocoder
 from .data import MelFrontEnd, ClipSampler
+from .plain_hifigan import PlainHiFiGANGenerator
 
 __all__ = [
     "ODConv1d", "ODConvTranspose1d", "GRC_LoRA_Block", "FiLMLayer", "MultiReceptiveFieldBlock",
     "ModifiedHiFiGANGenerator", "HiFiGANGenerator", "GroupedResidualConv1D", "FeatureWiseLinearModulation",
     "HiFiGANDiscriminators", "MultiPeriodDiscriminator", "MultiScaleDiscriminator", "Discriminator1D",
     "Discriminator2D", "ModifiedHiFiGANVocoder", "VocoderTrainer", "ConditionedHiFiGAN", "HiFiGANTrainer",
-    "ChunkedVocoder", "MelFrontEnd", "ClipSampler",
+    "ChunkedVocoder", "MelFrontEnd", "ClipSampler", "PlainHiFiGANGenerator",
 ]

@@ -439,3 +439,26 @@ def rel_l2(a: Tensor, b: Tensor) -> float:
     """||a-b|| / ||b|| in float64."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# --------------------------------------------------------------------------------------- plain HiFi-GAN V3 (configs[0])
+def plain_hifigan_forward(mel: Tensor, sd: Dict[str, Tensor], upsample_rates=(8, 8, 4), upsample_kernel_sizes=(16, 16, 8),
+                          resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12))) -> Tensor:
+    """CPU restatement of the published HiFi-GAN V3 generator (Kong et al. 2020, ResBlock2).  The reference only imports
+    it from fairseq 0.12.2 (agent/tts/vocoder.py:24), which is absent here: PARITY UNPINNED - this function checks the
+    HIP path's self-consistency, nothing more.  sd keys: conv_pre, ups.{i}, resblocks.{j}.convs.{k}, conv_post."""
+    x = F.conv1d(mel, sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    nk = len(resblock_kernel_sizes)
+    for i, (u, k) in enumerate(zip(upsample_rates, upsample_kernel_sizes)):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j, (ks, ds) in enumerate(zip(resblock_kernel_sizes, resblock_dilation_sizes)):
+            r = x
+            for q, d in enumerate(ds):
+                pre = f"resblocks.{i * nk + j}.convs.{q}"
+                r = r + F.conv1d(F.leaky_relu(r, 0.1), sd[pre + ".weight"], sd[pre + ".bias"], dilation=d, padding=(ks - 1) * d // 2)
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x, 0.01)
+    return torch.tanh(F.conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3))
