@@ -19,13 +19,12 @@ __global__ __launch_bounds__(256) void conv_out_tanh_kernel(const T* __restrict_
   const int rows = 256 + ks - 1;
   constexpr int CPR = C * ES / 16;
   const T* xb = x + (size_t)b * Tn * C;
-  for (int i = tid; i < rows * CPR; i += 256) {
+  stage_batched<9, 256>(tid, rows * CPR, lds, [&](int i, const void*& src, int& dst) {
     const int r = i / CPR, ch = i % CPR;
     const int t = t0 - pad + r;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (t >= 0 && t < Tn) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xb + (size_t)t * C) + ch * 16);
-    *reinterpret_cast<u32x4*>(lds + (size_t)r * RS + ch * 16) = v;
-  }
+    if (t >= 0 && t < Tn) src = reinterpret_cast<const char*>(xb + (size_t)t * C) + ch * 16;
+    dst = r * RS + ch * 16;
+  });
   __syncthreads();
   float acc0 = bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   for (int j = 0; j < ks; ++j) {

@@ -174,4 +174,27 @@ __host__ __device__ inline int lds_row_stride(int row_bytes, int elem_size) {
   return row_bytes + 16;
 }
 
+// Global -> LDS staging with UB 16-byte loads per thread in flight.  A plain `load; store` loop makes the compiler wait
+// for every load before the LDS store, i.e. one full memory latency per 16 bytes and thread.  f(i, src, dst) maps the
+// linear piece index i to its source pointer (nullptr = zero fill) and its LDS byte offset.
+template <int UB, int NT, typename F>
+__device__ __forceinline__ void stage_batched(int tid, int total, char* lds_base, F f) {
+  for (int i0 = tid; i0 < total; i0 += NT * UB) {
+    u32x4 v[UB];
+    int d[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int i = i0 + u * NT;
+      const void* src = nullptr;
+      d[u] = -1;
+      if (i < total) f(i, src, d[u]);
+      v[u] = u32x4{0u, 0u, 0u, 0u};
+      if (src) v[u] = *reinterpret_cast<const u32x4*>(src);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (d[u] >= 0) *reinterpret_cast<u32x4*>(lds_base + d[u]) = v[u];
+  }
+}
+
 }  // namespace mv

@@ -155,15 +155,14 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   {
     const int cpr = p.Cin * ES / 16;
     const int per = p.nrows * cpr;
-    for (int i = tid; i < S * per; i += 256) {
-      const int s = i / per, rem = i % per;
-      const int r = rem / cpr, ch = rem % cpr;
+    stage_batched<4, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
+      const int s = i / per, rem = i - s * per;
+      const int r = rem / cpr, ch = rem - r * cpr;
       const int tin = q0 + p.shift_lo + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
       if (b0 + s < p.B && tin >= 0 && tin < p.Tin)
-        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
-      *reinterpret_cast<u32x4*>(xl + ((long)s * p.nrows + r) * RS + ch * 16) = v;
-    }
+        src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
+      dst = (s * p.nrows + r) * RS + ch * 16;
+    });
   }
   __syncthreads();
 
@@ -380,15 +379,14 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   {
     const int cpr = p.Cin * ES / 16;
     const int per = p.nrows * cpr;
-    for (int i = tid; i < S * per; i += 256) {
-      const int s = i / per, rem = i % per;
-      const int r = rem / cpr, ch = rem % cpr;
+    stage_batched<8, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
+      const int s = i / per, rem = i - s * per;
+      const int r = rem / cpr, ch = rem - r * cpr;
       const int tin = p.shift_lo + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
       if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
-        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
-      *reinterpret_cast<u32x4*>(xl + ((long)s * p.nrows + r) * RS + ch * 16) = v;
-    }
+        src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
+      dst = (s * p.nrows + r) * RS + ch * 16;
+    });
   }
   __syncthreads();
 
