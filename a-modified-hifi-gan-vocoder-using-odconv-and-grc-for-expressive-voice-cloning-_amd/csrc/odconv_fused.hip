@@ -16,6 +16,7 @@
 // The x tiles of the S samples live in LDS (row stride padded by 16 B); bank weights stream from L2 in packed
 // A-fragment order (one coalesced 1 KB load per bank per fragment) and are reused for the S samples.
 #include "mfma.h"
+#include <cstdio>
 
 namespace mv {
 
@@ -104,6 +105,12 @@ __global__ __launch_bounds__(256) void odconv_pack_kernel(const P* __restrict__ 
   }
 }
 
+#ifdef MV_OD_TIMING
+__device__ long long* od_dbg = nullptr;
+#define OD_TM() do { if (ntm < 8) tmk[ntm++] = clock64(); } while (0)
+#else
+#define OD_TM() do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int S, int MW, int NB, bool PF, int KB>
 __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
@@ -119,6 +126,10 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha (KB <= OD_MAXK banks used)
   char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
   const int RS = lds_row_stride(p.Cin * ES, ES);
+#ifdef MV_OD_TIMING
+  long long tmk[8]; int ntm = 0;
+#endif
+  OD_TM();
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
@@ -151,6 +162,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
     }
   }
+  OD_TM();
   // ---- stage x tiles: input rows q0+shift_lo .. +nrows-1 of every sample, zero outside [0,Tin)
   {
     const int cpr = p.Cin * ES / 16;
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
     });
   }
   __syncthreads();
+  OD_TM();
 
   float al[S][KB];
 #pragma unroll
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
     while (c8 >= cpc) { c8 -= cpc; ++tap; }
   }
 
+  OD_TM();
   // ---- epilogue: bias, FiLM, activation -> LDS tile [s][q][rows of this workgroup] -> whole-row 16-byte stores
   __syncthreads();                                   // every wave is done with the x tiles: reuse the region
   constexpr int RW = 4 * MW * 16;                    // GEMM rows covered by this workgroup
@@ -307,6 +321,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       }
     }
   }
+  OD_TM();
   __syncthreads();
   {
     constexpr int EPC = 16 / ES;                     // elements per 16-byte chunk
@@ -324,6 +339,13 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
     }
   }
+#ifdef MV_OD_TIMING
+  OD_TM();
+  if (tid == 0 && od_dbg) {
+    const long wgid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wgid < 8192) for (int i = 0; i < 8; ++i) od_dbg[wgid * 8 + i] = i < ntm ? tmk[i] - tmk[0] : -1;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ K-loop variant
@@ -584,8 +606,27 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
   }
   dim3 grid(cdiv(p.nq, NB * 16), cdiv(p.M / 16, 4 * MW), cdiv(p.B, S));
   if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
+#ifdef MV_OD_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 8192 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(od_dbg), &dbg, sizeof(dbg)); }
+  hipMemsetAsync(dbg, 0xff, 8192 * 8 * 8, stream);
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
                      (const T*)att_w, (const T*)att_b, (const T*)film, (T*)y, pooled_out, p);
+#ifdef MV_OD_TIMING
+  if (++calls == 20) {
+    hipStreamSynchronize(stream);
+    static long long hbuf[8192 * 8];
+    hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+    const long nwg = (long)grid.x * grid.y * grid.z < 8192 ? (long)grid.x * grid.y * grid.z : 8192;
+    double avg[8] = {0}; int cnt[8] = {0};
+    for (long w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) { long long v = hbuf[w * 8 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
+    fprintf(stderr, "[od timing] Cin %d M %d ksteps %d grid %u x %u x %u marks:", p.Cin, p.M, p.ksteps, grid.x, grid.y, grid.z);
+    for (int i = 0; i < 8; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
   return MV_OK;
 }
 
