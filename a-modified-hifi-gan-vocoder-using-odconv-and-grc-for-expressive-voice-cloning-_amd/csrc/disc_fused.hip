@@ -212,12 +212,12 @@ __global__ __launch_bounds__(256) void dhead_pack_kernel(const P* __restrict__ w
   }
 }
 
-template <typename T>
+template <typename T, int C>
 __global__ __launch_bounds__(256) void dhead_z_kernel(const T* __restrict__ x, const T* __restrict__ pf, float* __restrict__ z,
                                                       long npos, int taps) {
   using M = Mma<T>;
   using V = typename M::V;
-  constexpr int KS = DH_C / 32;
+  constexpr int KS = C / 32;
   const int lane = threadIdx.x & 63, col = lane & 15, g = lane >> 4;
   V a[KS];
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void dhead_z_kernel(const T* __restrict__ x, c
   for (long grp = wave; grp < ngroups; grp += nwaves) {
     const long pos = grp * 16 + col;
     const long pc = pos < npos ? pos : npos - 1;
-    const char* xr = reinterpret_cast<const char*>(x + pc * DH_C) + g * 16;
+    const char* xr = reinterpret_cast<const char*>(x + pc * C) + g * 16;
     V bfr[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) bfr[ks] = M::load_b(xr + ks * 64);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void dhead_z_kernel(const T* __restrict__ x, c
 
 template <typename T>
 __global__ __launch_bounds__(256) void dhead_sum_kernel(const float* __restrict__ z, const T* __restrict__ bias, T* __restrict__ y,
-                                                        int B, int H, int W, int kh, int kw) {
+                                                        int B, int H, int W, int kh, int kw, int flip) {
   const long npos = (long)B * H * W;
   const int ph = kh / 2, pw = kw / 2;
   const float bv = bias ? ld<T>(bias) : 0.f;
@@ -252,12 +252,12 @@ __global__ __launch_bounds__(256) void dhead_sum_kernel(const float* __restrict_
     const int w = (int)(i % W), h = (int)((i / W) % H);
     float acc = bv;
     for (int ih = 0; ih < kh; ++ih) {
-      const int hh = h + ih - ph;
+      const int dh = flip ? -(ih - ph) : ih - ph, hh = h + dh;     // flip: the adjoint (data gradient) reaches pos - off(tap)
       if (hh < 0 || hh >= H) continue;
       for (int iw = 0; iw < kw; ++iw) {
-        const int ww = w + iw - pw;
+        const int dw = flip ? -(iw - pw) : iw - pw, ww = w + dw;
         if (ww < 0 || ww >= W) continue;
-        acc += z[(long)(ih * kw + iw) * npos + i + (long)(ih - ph) * W + (iw - pw)];
+        acc += z[(long)(ih * kw + iw) * npos + i + (long)dh * W + dw];
       }
     }
     st<T>(y + i, acc);
@@ -402,26 +402,33 @@ __global__ __launch_bounds__(256) void dtap_wgrad_kernel(const T* __restrict__ v
     __syncthreads();
     const int wend = (w0 + WT < W) ? w0 + WT : W;
     const T* vrow = vec + (((long)b * H + h) * W) * C + cg * 8;
-    for (int w = w0 + part; w < wend; w += nparts) {
-      T tmp[8];
+    // two positions per iteration: both 16-byte loads are issued before the FMAs of either
+    for (int w = w0 + part; w < wend; w += 2 * nparts) {
+      const int w2 = w + nparts;
+      const bool two = w2 < wend;
+      alignas(16) T tmp[8];
+      alignas(16) T tmp2[8];
       *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(vrow + (long)w * C);
-      float v[8];
+      *reinterpret_cast<u32x4*>(tmp2) = two ? *reinterpret_cast<const u32x4*>(vrow + (long)w2 * C) : u32x4{0u, 0u, 0u, 0u};
+      float v[8], v2[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ld<T>(tmp + e);
+      for (int e = 0; e < 8; ++e) { v[e] = ld<T>(tmp + e); v2[e] = ld<T>(tmp2 + e); }
       const float* wp = win + (w - w0) + (flip ? 2 * PW : 0);
+      const float* wp2 = two ? wp + nparts : wp;          // v2 is zero when the second position does not exist
 #pragma unroll
       for (int ih = 0; ih < KH; ++ih)
 #pragma unroll
         for (int iw = 0; iw < KW; ++iw) {
           const float sv = flip ? wp[ih * gwid - iw] : wp[ih * gwid + iw];
+          const float sv2 = flip ? wp2[ih * gwid - iw] : wp2[ih * gwid + iw];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[ih * KW + iw][e] += v[e] * sv;
+          for (int e = 0; e < 8; ++e) acc[ih * KW + iw][e] += v[e] * sv + v2[e] * sv2;
         }
       if (bias_mode == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bacc[e] += v[e];
+        for (int e = 0; e < 8; ++e) bacc[e] += v[e] + v2[e];
       } else if (bias_mode == 2 && cg == 0) {
-        bsum += win[PH * gwid + (w - w0) + PW];
+        bsum += win[PH * gwid + (w - w0) + PW] + (two ? win[PH * gwid + (w2 - w0) + PW] : 0.f);
       }
     }
   }
@@ -649,6 +656,63 @@ __global__ __launch_bounds__(256) void dfirst_fwd_kernel(const T* __restrict__ x
   }
 }
 
+// register-tiled forward: a thread owns 8 output channels (their KH*KW weights live in registers) and walks the positions
+// of the workgroup's row chunk; the one-channel input window sits in LDS; 16-byte channels-last stores
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void dfirst_fwd_tiled_kernel(const T* __restrict__ x0, const T* __restrict__ w, const T* __restrict__ bias,
+                                                               T* __restrict__ y, int H, int W, int C1, float slope, int WT, int wsplit) {
+  constexpr int TAPS = KH * KW, PH = KH / 2, PW = KW / 2;
+  extern __shared__ float win[];                     // [KH][WT + KW - 1]
+  const int gwid = WT + KW - 1;
+  const int tid = threadIdx.x;
+  const int tpr = C1 / 8, cg = tid % tpr, part = tid / tpr, nparts = 256 / tpr;
+  const int chunk = blockIdx.x, bh = chunk / wsplit, wc = chunk - bh * wsplit;
+  const int b = bh / H, h = bh - b * H, w0 = wc * WT;
+  for (int i = tid; i < KH * gwid; i += 256) {
+    const int ih = i / gwid, j = i - ih * gwid;
+    const int hh = h + ih - PH, ww = w0 - PW + j;
+    win[i] = (hh >= 0 && hh < H && ww >= 0 && ww < W) ? ld<T>(x0 + ((long)b * H + hh) * W + ww) : 0.f;
+  }
+  float wr[TAPS][8], bv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    bv[e] = bias ? ld<T>(bias + cg * 8 + e) : 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) wr[t][e] = ld<T>(w + (long)(cg * 8 + e) * TAPS + t);
+  }
+  __syncthreads();
+  const int wend = (w0 + WT < W) ? w0 + WT : W;
+  T* yrow = y + (((long)b * H + h) * W) * C1 + cg * 8;
+  for (int wx = w0 + part; wx < wend; wx += nparts) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bv[e];
+    const float* wp = win + (wx - w0);
+#pragma unroll
+    for (int ih = 0; ih < KH; ++ih)
+#pragma unroll
+      for (int iw = 0; iw < KW; ++iw) {
+        const float xv = wp[ih * gwid + iw];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wr[ih * KW + iw][e] * xv;
+      }
+    alignas(16) T ov[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st<T>(ov + e, acc[e] >= 0.f ? acc[e] : acc[e] * slope);
+    *reinterpret_cast<u32x4*>(yrow + (long)wx * C1) = *reinterpret_cast<u32x4*>(ov);
+  }
+}
+
+// data-gradient operator of the first layer for the tap-row z-GEMM (dhead_z_kernel<T, 32>): row = tap, k = channel
+template <typename T>
+__global__ void dfirst_dpack_kernel(const T* __restrict__ w, T* __restrict__ pf, int C1, int taps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (C1 / 32) * 512) return;
+  const int j = idx % 8, lane = (idx / 8) % 64, ks = idx / 512;
+  const int tap = lane & 15, c = 32 * ks + 8 * (lane >> 4) + j;
+  pf[idx] = tap < taps ? w[(long)c * taps + tap] : T(0.f);
+}
+
 // data gradient: gx0[pos] = sum_{o,tap} w[o][tap] g1[pos - tap][o]   (g1 = d/d pre-activation, [B][H][W][C1]); one wave per position
 template <typename T>
 __global__ __launch_bounds__(256) void dfirst_dgrad_kernel(const T* __restrict__ g1, const T* __restrict__ w, T* __restrict__ gx0,
@@ -850,9 +914,9 @@ static void dhead_fwd_launch(const void* x, const void* packed, const void* bias
   const long npos = (long)B * H * W;
   const long groups = (npos + 15) / 16;
   const int grid = (int)((groups + 3) / 4 > 4096 ? 4096 : (groups + 3) / 4);
-  hipLaunchKernelGGL(dhead_z_kernel<T>, dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)packed, ws, npos, kh * kw);
+  hipLaunchKernelGGL((dhead_z_kernel<T, DH_C>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)packed, ws, npos, kh * kw);
   hipLaunchKernelGGL(dhead_sum_kernel<T>, dim3((unsigned)((npos + 255) / 256 > 4096 ? 4096 : (npos + 255) / 256)), dim3(256), 0, s,
-                     ws, (const T*)bias, (T*)y, B, H, W, kh, kw);
+                     ws, (const T*)bias, (T*)y, B, H, W, kh, kw, 0);
 }
 
 extern "C" int mv_dhead_fwd(const void* x, const void* packed, const void* bias, float* workspace, void* y, int B, int H, int W,
@@ -968,6 +1032,23 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
 extern "C" int mv_dfirst_fwd_cl(const void* x0, const void* w, const void* bias, void* y, int B, int H, int W, int C1, int kh,
                                 int kw, float slope, int dtype, void* stream) {
   MV_CHECK_ARG(x0 && w && y && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0);
+  const bool tiled = C1 % 8 == 0 && C1 <= 2048 && 256 % (C1 / 8) == 0 && ((uintptr_t)y & 15) == 0 &&
+                     ((kh == 3 && kw == 3) || (kh == 1 && kw == 15)) && dtype != MV_F32;
+  if (tiled) {
+    const int WT = 1024, wsplit = cdiv(W, WT);
+    const long nchunks = (long)B * H * wsplit;
+    if (nchunks <= (1L << 30)) {
+      const size_t lds = sizeof(float) * (size_t)kh * (WT + kw - 1);
+      hipStream_t s = (hipStream_t)stream;
+#define MV_DF(TT) do { \
+        if (kh == 3) hipLaunchKernelGGL((dfirst_fwd_tiled_kernel<TT, 3, 3>), dim3((unsigned)nchunks), dim3(256), lds, s, (const TT*)x0, (const TT*)w, (const TT*)bias, (TT*)y, H, W, C1, slope, WT, wsplit); \
+        else hipLaunchKernelGGL((dfirst_fwd_tiled_kernel<TT, 1, 15>), dim3((unsigned)nchunks), dim3(256), lds, s, (const TT*)x0, (const TT*)w, (const TT*)bias, (TT*)y, H, W, C1, slope, WT, wsplit); } while (0)
+      if (dtype == MV_BF16) MV_DF(bf16); else MV_DF(f16);
+#undef MV_DF
+      MV_LAUNCH_CHECK();
+      return MV_OK;
+    }
+  }
   const long n = (long)H * W * C1;
   dim3 grid((unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256), B);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x0, (const T*)w,
@@ -976,9 +1057,30 @@ extern "C" int mv_dfirst_fwd_cl(const void* x0, const void* w, const void* bias,
   return MV_OK;
 }
 
-extern "C" int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, int B, int H, int W, int C1, int kh, int kw,
-                                  int dtype, void* stream) {
+extern "C" size_t mv_dfirst_dgrad_workspace_bytes(int B, int H, int W) { return sizeof(float) * 16 * (size_t)B * H * W + 4096; }
+
+template <typename T>
+static void dfirst_dgrad_mfma(const void* g1, const void* w, void* gx0, float* ws, int B, int H, int W, int kh, int kw, hipStream_t s) {
+  const long npos = (long)B * H * W;
+  T* pk = reinterpret_cast<T*>(reinterpret_cast<char*>(ws) + sizeof(float) * 16 * (size_t)npos);   // 1 KB packed operator behind z
+  hipLaunchKernelGGL(dfirst_dpack_kernel<T>, dim3(2), dim3(256), 0, s, (const T*)w, pk, 32, kh * kw);
+  const long groups = (npos + 15) / 16;
+  const int grid = (int)((groups + 3) / 4 > 4096 ? 4096 : (groups + 3) / 4);
+  hipLaunchKernelGGL((dhead_z_kernel<T, 32>), dim3(grid), dim3(256), 0, s, (const T*)g1, (const T*)pk, ws, npos, kh * kw);
+  hipLaunchKernelGGL(dhead_sum_kernel<T>, dim3((unsigned)((npos + 255) / 256 > 4096 ? 4096 : (npos + 255) / 256)), dim3(256), 0, s,
+                     ws, (const T*)nullptr, (T*)gx0, B, H, W, kh, kw, 1);
+}
+
+extern "C" int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, float* workspace, int B, int H, int W, int C1, int kh,
+                                  int kw, int dtype, void* stream) {
   MV_CHECK_ARG(g1 && w && gx0 && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0);
+  if (workspace && C1 == 32 && kh * kw <= 16 && dtype != MV_F32 && ((uintptr_t)g1 & 15) == 0) {
+    // taps on the MFMA rows: z[tap][pos] = sum_o w[o][tap] g1[pos][o], then gx0[pos] = sum_tap z[tap][pos - off(tap)]
+    if (dtype == MV_BF16) dfirst_dgrad_mfma<bf16>(g1, w, gx0, workspace, B, H, W, kh, kw, (hipStream_t)stream);
+    else dfirst_dgrad_mfma<f16>(g1, w, gx0, workspace, B, H, W, kh, kw, (hipStream_t)stream);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   dim3 grid((unsigned)(((long)H * W + 3) / 4), B);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(dfirst_dgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g1, (const T*)w,
                                         (T*)gx0, H, W, C1, kh, kw));

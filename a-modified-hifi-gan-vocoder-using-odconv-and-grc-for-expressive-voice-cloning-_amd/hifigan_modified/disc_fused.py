@@ -198,7 +198,8 @@ class _DiscStack(Function):
         gx0 = None
         if need[0]:
             gx0 = torch.empty_like(x0)
-            N.call("mv_dfirst_dgrad_cl", _P(g), _P(_cache.get(params[0], dt)), _P(gx0), B, H, W, C1, kh, kw, ops._dt(g), st())
+            ws = torch.empty(N.lib().mv_dfirst_dgrad_workspace_bytes(B, H, W) // 4, device=dev, dtype=torch.float32)
+            N.call("mv_dfirst_dgrad_cl", _P(g), _P(_cache.get(params[0], dt)), _P(gx0), _P(ws), B, H, W, C1, kh, kw, ops._dt(g), st())
         return (gx0, None, *grads)
 
 

@@ -306,8 +306,9 @@ int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace,
  * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */
 int mv_dfirst_fwd_cl(const void* x0, const void* w, const void* bias, void* y, int B, int H, int W, int C1, int kh,
                      int kw, float slope, int dtype, void* stream);
-int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, int B, int H, int W, int C1, int kh, int kw, int dtype,
-                       void* stream);
+size_t mv_dfirst_dgrad_workspace_bytes(int B, int H, int W);
+int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, float* workspace, int B, int H, int W, int C1, int kh, int kw,
+                       int dtype, void* stream);
 int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int B, int H, int W, int C1, int kh, int kw,
                        int dtype, void* stream);
 /* out[c] = sum over rows of x[row][c] (bias gradient of a channels-last tensor); C divides 256. */
