@@ -489,8 +489,8 @@ static int dtap_launch(const void* vec, const void* sc, float* gw, float* gb, in
 // the tap-major workspace, lanes along c -> 64-byte segments), then dconv_wgrad_reorder_kernel writes [o][c][tap].
 template <typename T, int TAPS_H, int TAPS_W, int WT>
 __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
-                                                          float* __restrict__ gws, int B, int H, int W, int Cin, int Cout,
-                                                          int wsplit, int nchunks, int chunks_per_wg, int dil) {
+                                                          float* __restrict__ gws, float* __restrict__ gb, int B, int H, int W,
+                                                          int Cin, int Cout, int wsplit, int nchunks, int chunks_per_wg, int dil) {
   static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
   using M = Mma<T>;
   typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -566,6 +566,9 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
     }
   };
 
+  // bias gradient gb[o] = sum_pos g[pos][o] rides along: the g tile is already in LDS (first Cin tile's workgroups only)
+  const bool do_gb = gb != nullptr && blockIdx.x == 0;
+  float bsum = 0.f;
   const int cbeg = blockIdx.z * chunks_per_wg;
   int cend = cbeg + chunks_per_wg; if (cend > nchunks) cend = nchunks;
   if (cbeg < cend) { issue(cbeg); commit(0); }
@@ -575,6 +578,11 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
     const bool more = chunk + 1 < cend;                 // uniform across the workgroup
     if (more) issue(chunk + 1);
     const char* base = lds + buf * BUF;
+    if (do_gb) {
+      const T* gcol = reinterpret_cast<const T*>(base) + (tid & 63);
+#pragma unroll
+      for (int r = tid >> 6; r < WT; r += 8) bsum += ld<T>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(gcol) + r * RS));
+    }
 #pragma unroll 1
     for (int k0 = 0; k0 < WT; k0 += 32) {
       typename M::V a[2];
@@ -603,6 +611,7 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
     __syncthreads();
     buf ^= 1;
   }
+  if (do_gb && o0 + (tid & 63) < Cout) atomicAdd(gb + o0 + (tid & 63), bsum);
   // D[row = o (4*grp + r)][col = c (li)] -> gws[tap][o][c]
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -972,7 +981,7 @@ extern "C" size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int 
 }
 
 template <typename T, int TH, int TW_, int WT>
-static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H, int W, int Cin, int Cout, int dil, hipStream_t s) {
+static int dwgrad_launch(const void* x, const void* g, float* gws, float* gb, int B, int H, int W, int Cin, int Cout, int dil, hipStream_t s) {
   const int wsplit = cdiv(W, WT);
   const int halo = (TW_ - 1) * dil;
   if (halo > (TH == 1 ? 64 : TW_ - 1)) return MV_ERR_UNSUPPORTED;
@@ -991,36 +1000,37 @@ static int dwgrad_launch(const void* x, const void* g, float* gws, int B, int H,
   const int cpw = (int)((nchunks + groups - 1) / groups);
   groups = (int)((nchunks + cpw - 1) / cpw);
   dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), groups);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw, dil);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, gb, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw, dil);
   return MV_OK;
 }
 
 template <typename T>
-static int dwgrad_dispatch(const void* x, const void* g, float* ws, int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil,
-                           hipStream_t s) {
-  if (kh == 3 && kw == 3) return dil == 1 ? dwgrad_launch<T, 3, 3, 64>(x, g, ws, B, H, W, Cin, Cout, 1, s) : MV_ERR_UNSUPPORTED;
+static int dwgrad_dispatch(const void* x, const void* g, float* ws, float* gb, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                           int dil, hipStream_t s) {
+  if (kh == 3 && kw == 3) return dil == 1 ? dwgrad_launch<T, 3, 3, 64>(x, g, ws, gb, B, H, W, Cin, Cout, 1, s) : MV_ERR_UNSUPPORTED;
   if (kh != 1) return MV_ERR_UNSUPPORTED;
   switch (kw) {
-    case 1: return dwgrad_launch<T, 1, 1, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
-    case 3: return dwgrad_launch<T, 1, 3, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
-    case 5: return dwgrad_launch<T, 1, 5, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
-    case 7: return dwgrad_launch<T, 1, 7, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
-    case 11: return dwgrad_launch<T, 1, 11, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
-    case 15: return dwgrad_launch<T, 1, 15, 128>(x, g, ws, B, H, W, Cin, Cout, dil, s);
+    case 1: return dwgrad_launch<T, 1, 1, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
+    case 3: return dwgrad_launch<T, 1, 3, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
+    case 5: return dwgrad_launch<T, 1, 5, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
+    case 7: return dwgrad_launch<T, 1, 7, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
+    case 11: return dwgrad_launch<T, 1, 11, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
+    case 15: return dwgrad_launch<T, 1, 15, 128>(x, g, ws, gb, B, H, W, Cin, Cout, dil, s);
     default: return MV_ERR_UNSUPPORTED;
   }
 }
 
-extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin,
+extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* gb, float* workspace, int B, int H, int W, int Cin,
                                  int Cout, int kh, int kw, int dil_w, int dtype, void* stream) {
   MV_CHECK_ARG(x && g && gw && workspace && B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && dil_w >= 1);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
   if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;   // 16-bit storage only (transposed LDS reads); callers fall back to the generic kernel
   hipStream_t s = (hipStream_t)stream;
   hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, s);
+  if (gb) hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Cout, s);
   int rc = MV_ERR_UNSUPPORTED;
-  if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, B, H, W, Cin, Cout, kh, kw, dil_w, s);
-  else if (dtype == MV_F16) rc = dwgrad_dispatch<f16>(x, g, workspace, B, H, W, Cin, Cout, kh, kw, dil_w, s);
+  if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, gb, B, H, W, Cin, Cout, kh, kw, dil_w, s);
+  else if (dtype == MV_F16) rc = dwgrad_dispatch<f16>(x, g, workspace, gb, B, H, W, Cin, Cout, kh, kw, dil_w, s);
   if (rc != MV_OK) return rc;
   const long total = (long)Cout * Cin * kh * kw;
   hipLaunchKernelGGL(dconv_wgrad_reorder_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),

@@ -179,11 +179,9 @@ class _DiscStack(Function):
         for li in (3, 2, 1):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             if need_w:
-                gw = f32(Cout, Cin, kh, kw)
-                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(f32(kh * kw, Cout, Cin)), B, H, W, Cin, Cout, kh, kw, 1,
+                gw, gb = f32(Cout, Cin, kh, kw), f32(Cout)
+                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(gb), _P(f32(kh * kw, Cout, Cin)), B, H, W, Cin, Cout, kh, kw, 1,
                        ops._dt(g), st())
-                gb = f32(Cout)
-                N.call("mv_colsum_cl", _P(g), _P(gb), B * H * W, Cout, ops._dt(g), st())
                 grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])
             gprev = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
             N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(params[2 * li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,

@@ -164,14 +164,18 @@ class _Conv1d(Function):
                 gx_cl = ops.dconv_cl(g_cl, ops.dconv_pack(weight.reshape(Cout, Cin, 1, ks), gy.dtype, 1, cop, cip), None, cip, 1, ks,
                                      dilation)
                 gx = ops.ntc_to_nct(gx_cl, Cin)
+            need_b = bias is not None and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
-                gwp = ops.dconv_wgrad_cl(x, g_cl, 1, ks, dilation).view(cop, cip, ks)
+                gwp, gbp = ops.dconv_wgrad_cl(x, g_cl, 1, ks, dilation, want_bias=True)
+                gwp = gwp.view(cop, cip, ks)
                 if (cop, cip) != (Cout, Cin):
                     gwc = torch.empty(Cout, Cin, ks, device=gwp.device, dtype=gwp.dtype)
                     ops.copy_rows(gwp.view(1, cop, cip * ks)[:, :Cout], gwc.view(1, Cout, Cin * ks))
                     gwp = gwc
                 gw = _to(gwp, weight)
-            if bias is not None and ctx.needs_input_grad[2]:
+                if need_b:
+                    gb = _to(gbp[:Cout], bias)
+            elif need_b:
                 gb = _to(ops.bias_grad(gy), bias)
             return gx, gw, gb, None
         if groups != 1:

@@ -332,15 +332,16 @@ def dconv_cl(x_cl, packed, bias, Cout, kh, kw, dil=1, act=N.ACT_NONE, slope=0.1,
     return y
 
 
-def dconv_wgrad_cl(x_cl, g_cl, kh, kw, dil=1):
-    """fp32 [Cout,Cin,kh,kw] = sum_pos g x (transposed-LDS-read MFMA GEMM)."""
+def dconv_wgrad_cl(x_cl, g_cl, kh, kw, dil=1, want_bias=False):
+    """fp32 [Cout,Cin,kh,kw] = sum_pos g x (transposed-LDS-read MFMA GEMM); with want_bias also gb fp32 [Cout] = sum_pos g."""
     shp = x_cl.shape
     B, H, W, Cin = (shp[0], 1, shp[1], shp[2]) if x_cl.dim() == 3 else shp
     Cout = g_cl.shape[-1]
     gw = _f32(Cout, Cin, kh, kw, device=x_cl.device)
+    gb = _f32(Cout, device=x_cl.device) if want_bias else None
     ws = _f32(kh * kw, Cout, Cin, device=x_cl.device)
-    N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
-    return gw
+    N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(gb), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
+    return (gw, gb) if want_bias else gw
 
 
 def colsum_cl(g_cl):

@@ -276,6 +276,7 @@ int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr
  *   mv_dhead_*: the Cout = 1 layer (weights as fp32 [kh*kw][C] from mv_conv_out_pack-style transposition).
  *   mv_dconv_wgrad_cl: gw fp32 [Cout][Cin][kh][kw] = sum g x (16-bit storage only; 3x3, and 1xk for k in 1,3,5,7,11,15
  *     with W-dilation dil_w, (k-1)*dil_w <= 64 - the GRC/MRF convs of grc_lora.py:36-41 run through the same kernels);
+ *     gb (optional, fp32 [Cout]): the bias gradient sum_pos g[pos][o], accumulated from the LDS-resident g tiles;
  *     workspace: mv_dconv_wgrad_workspace_bytes() of device scratch (tap-major partial sums). */
 size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype);
 int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip, int dtype,
@@ -299,8 +300,8 @@ int mv_dhead_dgrad(const void* g, const void* packed, const void* xsave, void* g
 int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
                    int dtype, void* stream);
 size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int kw);
-int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* workspace, int B, int H, int W, int Cin, int Cout,
-                      int kh, int kw, int dil_w, int dtype, void* stream);
+int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* gb, float* workspace, int B, int H, int W, int Cin,
+                      int Cout, int kh, int kw, int dil_w, int dtype, void* stream);
 
 /* First discriminator layer (1 -> C1 channels, LeakyReLU), channels-last output, and its gradients
  * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */

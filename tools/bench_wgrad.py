@@ -37,7 +37,7 @@ for (Hh, W, cin, cout, kh, kw) in cases:
     g = torch.randn(B, Hh, W, cout, device="cuda").to(dt)
     gw = torch.empty(cout, cin, kh, kw, device="cuda")
     ws = torch.empty(kh * kw, cout, cin, device="cuda")
-    fn = lambda: N.call("mv_dconv_wgrad_cl", _P(x), _P(g), _P(gw), _P(ws), B, Hh, W, cin, cout, kh, kw, 1, ops._dt(x), ops._stream())
+    fn = lambda: N.call("mv_dconv_wgrad_cl", _P(x), _P(g), _P(gw), None, _P(ws), B, Hh, W, cin, cout, kh, kw, 1, ops._dt(x), ops._stream())
     us = timeit(fn)
     fl = 2.0 * B * Hh * W * cin * cout * kh * kw
     # reference on a batch slice (fp32)
@@ -46,7 +46,7 @@ for (Hh, W, cin, cout, kh, kw) in cases:
     gr = g[:nb].float().permute(0, 3, 1, 2).contiguous()
     ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, kh, kw), gr, padding=(kh // 2, kw // 2))
     gw2 = torch.empty_like(gw)
-    N.call("mv_dconv_wgrad_cl", _P(x[:nb].contiguous()), _P(g[:nb].contiguous()), _P(gw2), _P(ws), nb, Hh, W, cin, cout, kh, kw, 1,
+    N.call("mv_dconv_wgrad_cl", _P(x[:nb].contiguous()), _P(g[:nb].contiguous()), _P(gw2), None, _P(ws), nb, Hh, W, cin, cout, kh, kw, 1,
            ops._dt(x), ops._stream())
     err = ((gw2 - ref).norm() / ref.norm()).item()
     tot += us
