@@ -184,6 +184,154 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   }
 }
 
+// Wide-input variant (Cin = 256: the data gradient of the 128->256 layer).  The whole-Cin tile of dconv_cl_kernel leaves room
+// for 4 column blocks and 4 waves per CU (one wave per SIMD, nothing to hide latency behind).  Here the input is staged in
+// 128-channel chunks, the tile keeps 128 positions, and 8 waves split it as 2 position halves x 4 row groups (2 M-tiles x 4
+// column blocks each): two waves per SIMD on the same LDS budget.  Weight k-steps are fetched two ahead, across chunks.
+template <typename T>
+__global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                            const T* __restrict__ bias, const T* __restrict__ actsave,
+                                                            T* __restrict__ y, DcP p) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int ES = M::ES, MW = 2, NB = 4, CCH = 128, NPOS = 128;
+  extern __shared__ __align__(16) char lds[];
+  const int RS = lds_row_stride(CCH * ES, ES);
+  const int prow = NPOS + (p.kw - 1) * p.dil;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int ps = wid >> 2, rg = wid & 3;                 // position half, row group
+  const int w0 = blockIdx.x * NPOS;
+  const int mt0 = (blockIdx.y * 4 + rg) * MW;
+  const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
+  const int n_mt = p.Cout / 16;
+  const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
+  const int taps = p.kh * p.kw, nchunks = p.Cin / CCH;
+
+  auto stage = [&](int ck) {
+    constexpr int UB = 8;
+    constexpr int cpr = CCH * ES / 16, rpp = 512 / cpr;
+    const int ch = tid % cpr;
+    const int nrow = p.kh * prow;
+    const char* xb = reinterpret_cast<const char*>(x + (long)b * p.H * p.W * p.Cin + (long)ck * CCH) + ch * 16;
+    for (int R0 = tid / cpr; R0 < nrow; R0 += rpp * UB) {
+      u32x4 v[UB];
+      int dsto[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int R = R0 + u * rpp;
+        int pl = 0, r = R;
+        while (r >= prow) { r -= prow; ++pl; }
+        const int hh = h - ph + pl, ww = w0 - pw + r;
+        v[u] = u32x4{0u, 0u, 0u, 0u};
+        dsto[u] = R < nrow ? R * RS + ch * 16 : -1;
+        if (R < nrow && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+          v[u] = *reinterpret_cast<const u32x4*>(xb + ((long)hh * p.W + ww) * p.Cin * ES);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (dsto[u] >= 0) *reinterpret_cast<u32x4*>(lds + dsto[u]) = v[u];
+    }
+  };
+
+  f32x4 acc[MW][NB];
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 16;
+  V a0[MW], a1[MW], a2[MW];
+  auto wfetch = [&](int kid, V (&dst)[MW]) {
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+      dst[mw] = M::load_b(wlane + ((long)mt * p.ksteps + kid) * 1024);
+    }
+  };
+  // k-steps in execution order: chunk-major, then tap, then the 4 channel blocks of the chunk
+  int fck = 0, ftap = 0, fj = 0, fetched = 0;
+  auto fetch_next = [&](V (&dst)[MW]) {
+    wfetch(ftap * p.cin32 + fck * (CCH / 32) + fj, dst);
+    ++fetched;
+    if (++fj == CCH / 32) { fj = 0; if (++ftap == taps) { ftap = 0; ++fck; } }
+  };
+  fetch_next(a0);
+  fetch_next(a1);
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck) __syncthreads();
+    stage(ck);
+    __syncthreads();
+    for (int tap = 0; tap < taps; ++tap) {
+      const int ih = tap / p.kw, iw = tap - ih * p.kw;
+      const char* brow = lds + ((long)ih * prow + iw * p.dil + ps * 64 + col) * RS + 8 * g * ES;
+#pragma unroll
+      for (int j = 0; j < CCH / 32; ++j) {
+        if (fetched < p.ksteps) fetch_next(a2);
+        V bf[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) bf[n] = M::load_b(brow + j * 32 * ES + (long)(n * 16) * RS);
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(a0[mw], bf[n], acc[mw][n]);
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw) { a0[mw] = a1[mw]; a1[mw] = a2[mw]; }
+      }
+    }
+  }
+
+  // ---- epilogue through LDS: [position][128 rows of this workgroup] -> whole-row stores
+  __syncthreads();
+  constexpr int RW = 4 * MW * 16;
+  constexpr int ORS = RW * ES + 16;
+  const int R0 = blockIdx.y * RW;
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw) {
+    const int mt = mt0 + mw;
+    if (mt < n_mt) {
+      const int row = 16 * mt + 4 * g;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = ld<T>(bias + row + i);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        float ov[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = apply_act(acc[mw][n][i] + bv[i], p.act, p.slope);
+        M::store4(lds + (long)(ps * 64 + n * 16 + col) * ORS + (row - R0) * ES, ov);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    constexpr int EPC = 16 / ES;
+    constexpr int CPR = RW / EPC;
+    T* yrow = y + (((long)b * p.H + h) * p.W) * p.Cout;
+    const T* srow = actsave ? actsave + (((long)b * p.H + h) * p.W) * p.Cout : nullptr;
+    for (int i = tid; i < NPOS * CPR; i += 512) {
+      const int ch = i % CPR, wi = i / CPR;
+      const int ww = w0 + wi, row = R0 + ch * EPC;
+      if (ww >= p.W || row >= p.Cout) continue;
+      u32x4 val = *reinterpret_cast<const u32x4*>(lds + (long)wi * ORS + ch * 16);
+      if (srow) {
+        alignas(16) T tmp[16 / ES];
+        alignas(16) T stmp[16 / ES];
+        *reinterpret_cast<u32x4*>(tmp) = val;
+        *reinterpret_cast<u32x4*>(stmp) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(srow + (long)ww * p.Cout + row));
+#pragma unroll
+        for (int e = 0; e < 16 / ES; ++e) {
+          const float gv = ld<T>(tmp + e);
+          st<T>(tmp + e, ld<T>(stmp + e) >= 0.f ? gv : gv * p.slope);
+        }
+        val = *reinterpret_cast<u32x4*>(tmp);
+      }
+      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(yrow + (long)ww * p.Cout + row)) = val;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ 256 -> 1 head
 // The head has ONE output channel, so the MFMA rows carry the TAPS instead:
 //   forward   z[tap][pos] = sum_c w[c][tap] x[pos][c]      (a 1x1 "conv" with 16 output rows = taps, K = C; x read once,
@@ -880,6 +1028,30 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0 && Cout % 8 == 0);
   DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w};
   int rc = MV_ERR_DTYPE;
+  if (dtype != MV_F32 && Cin % 128 == 0 && Cin > 128 && kh * kw * (Cin / 32) >= 2 && B * H <= 65535) {
+    // wide input: does the whole-Cin tile still fit 8 column blocks?  if not, the chunked 8-wave variant
+    const size_t full = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(Cin * 2, 2);
+    if (full > 160 * 1024) {
+      const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(128 * 2, 2);
+      const size_t ob = (size_t)128 * (128 * 2 + 16);
+      const size_t ldsb = xb > ob ? xb : ob;
+      if (ldsb <= 160 * 1024) {
+        static size_t lds_set_w[2] = {0, 0};
+        dim3 grid(cdiv(W, 128), cdiv(Cout / 16, 8), B * H);
+        if (dtype == MV_BF16) {
+          auto kern = dconv_cl_wide_kernel<bf16>;
+          if (ldsb > lds_set_w[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w[0] = ldsb; }
+          hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, (hipStream_t)stream, (const bf16*)x, (const bf16*)packed, (const bf16*)bias, (const bf16*)act_save, (bf16*)y, p);
+        } else {
+          auto kern = dconv_cl_wide_kernel<f16>;
+          if (ldsb > lds_set_w[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w[1] = ldsb; }
+          hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, (hipStream_t)stream, (const f16*)x, (const f16*)packed, (const f16*)bias, (const f16*)act_save, (f16*)y, p);
+        }
+        MV_LAUNCH_CHECK();
+        return MV_OK;
+      }
+    }
+  }
   MV_DISPATCH(dtype, {
     hipStream_t s_ = (hipStream_t)stream;
     if (Cout >= 256) {        // 8 waves cover all 256 rows: the x tile is staged once per column block
