@@ -22,6 +22,7 @@ struct DcP {
   float slope;
   int ksteps, cin32;
   int dil;                                        // dilation along W (1 for the discriminators; GRC convs use 1/3/5)
+  int cchunk;                                     // wide variant: input channels staged in LDS at a time
 };
 
 // packed[mt][kstep][lane][8]: row o = 16*mt + lane&15, k-chunk = 4*kstep + lane>>4 -> tap = chunk / (Cin/8), c = 8*(chunk % (Cin/8)) + j
@@ -188,21 +189,21 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
 // for 4 column blocks and 4 waves per CU (one wave per SIMD, nothing to hide latency behind).  Here the input is staged in
 // 128-channel chunks, the tile keeps 128 positions, and 8 waves split it as 2 position halves x 4 row groups (2 M-tiles x 4
 // column blocks each): two waves per SIMD on the same LDS budget.  Weight k-steps are fetched two ahead, across chunks.
-template <typename T>
+template <typename T, int PS, int MW, int NB, int CCH>
 __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                             const T* __restrict__ bias, const T* __restrict__ actsave,
                                                             T* __restrict__ y, DcP p) {
   using M = Mma<T>;
   using V = typename M::V;
-  constexpr int ES = M::ES, MW = 2, NB = 4, CCH = 128, NPOS = 128;
+  constexpr int ES = M::ES, RG = 8 / PS, NPOS = PS * NB * 16;   // PS position slices x RG row groups = 8 waves; CCH channels staged at a time
   extern __shared__ __align__(16) char lds[];
   const int RS = lds_row_stride(CCH * ES, ES);
   const int prow = NPOS + (p.kw - 1) * p.dil;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const int ps = wid >> 2, rg = wid & 3;                 // position half, row group
+  const int ps = wid / RG, rg = wid % RG;                // position slice, row group
   const int w0 = blockIdx.x * NPOS;
-  const int mt0 = (blockIdx.y * 4 + rg) * MW;
+  const int mt0 = (blockIdx.y * RG + rg) * MW;
   const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
   const int n_mt = p.Cout / 16;
   const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
@@ -250,23 +251,24 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
     }
   };
   // k-steps in execution order: chunk-major, then tap, then the 4 channel blocks of the chunk
+  constexpr int cc32 = CCH / 32;
   int fck = 0, ftap = 0, fj = 0, fetched = 0;
   auto fetch_next = [&](V (&dst)[MW]) {
-    wfetch(ftap * p.cin32 + fck * (CCH / 32) + fj, dst);
+    wfetch(ftap * p.cin32 + fck * cc32 + fj, dst);
     ++fetched;
-    if (++fj == CCH / 32) { fj = 0; if (++ftap == taps) { ftap = 0; ++fck; } }
+    if (++fj == cc32) { fj = 0; if (++ftap == taps) { ftap = 0; ++fck; } }
   };
   fetch_next(a0);
-  fetch_next(a1);
+  if (p.ksteps > 1) fetch_next(a1);
   for (int ck = 0; ck < nchunks; ++ck) {
     if (ck) __syncthreads();
     stage(ck);
     __syncthreads();
     for (int tap = 0; tap < taps; ++tap) {
       const int ih = tap / p.kw, iw = tap - ih * p.kw;
-      const char* brow = lds + ((long)ih * prow + iw * p.dil + ps * 64 + col) * RS + 8 * g * ES;
+      const char* brow = lds + ((long)ih * prow + iw * p.dil + ps * NB * 16 + col) * RS + 8 * g * ES;
 #pragma unroll
-      for (int j = 0; j < CCH / 32; ++j) {
+      for (int j = 0; j < cc32; ++j) {
         if (fetched < p.ksteps) fetch_next(a2);
         V bf[NB];
 #pragma unroll
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
 
   // ---- epilogue through LDS: [position][128 rows of this workgroup] -> whole-row stores
   __syncthreads();
-  constexpr int RW = 4 * MW * 16;
+  constexpr int RW = RG * MW * 16;
   constexpr int ORS = RW * ES + 16;
   const int R0 = blockIdx.y * RW;
 #pragma unroll
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
         float ov[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) ov[i] = apply_act(acc[mw][n][i] + bv[i], p.act, p.slope);
-        M::store4(lds + (long)(ps * 64 + n * 16 + col) * ORS + (row - R0) * ES, ov);
+        M::store4(lds + (long)(ps * NB * 16 + n * 16 + col) * ORS + (row - R0) * ES, ov);
       }
     }
   }
@@ -1026,31 +1028,41 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   MV_CHECK_ARG(x && packed && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 16 == 0 && (kh & 1) && (kw & 1));
   MV_CHECK_ARG(dil_w >= 1 && (kw - 1) * dil_w <= 128);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0 && Cout % 8 == 0);
-  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w};
+  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w, Cin};
   int rc = MV_ERR_DTYPE;
-  if (dtype != MV_F32 && Cin % 128 == 0 && Cin > 128 && kh * kw * (Cin / 32) >= 2 && B * H <= 65535) {
-    // wide input: does the whole-Cin tile still fit 8 column blocks?  if not, the chunked 8-wave variant
+  if (dtype != MV_F32 && B * H <= 65535) {
+    // 8-wave chunked variant: picked where it measured faster than the whole-Cin tile (tools/bench_dconv.py, B=32):
+    // every wide input (Cin > 128), and narrow outputs of 3x3 layers, where the whole-Cin kernel leaves waves idle
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("MV_DCONV_WIDE"); force = e ? atoi(e) : -1; }
     const size_t full = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(Cin * 2, 2);
-    if (full > 160 * 1024) {
-      const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(128 * 2, 2);
-      const size_t ob = (size_t)128 * (128 * 2 + 16);
+    bool use = full > 160 * 1024 || Cin > 128 || (kh == 3 && Cin >= 64 && Cout <= 128) || (kh == 1 && Cin == 64 && Cout == 32);
+    if (force >= 0) use = force != 0;
+    p.cchunk = Cin > 128 ? 128 : Cin;
+    if (use && Cin % p.cchunk == 0 && (p.cchunk == 128 || p.cchunk == 64 || p.cchunk == 32)) {
+      const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(p.cchunk * 2, 2);
+      const int rows = Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
+      const size_t ob = (size_t)128 * (rows * 2 + 16);
       const size_t ldsb = xb > ob ? xb : ob;
       if (ldsb <= 160 * 1024) {
-        static size_t lds_set_w[2] = {0, 0};
-        dim3 grid(cdiv(W, 128), cdiv(Cout / 16, 8), B * H);
-        if (dtype == MV_BF16) {
-          auto kern = dconv_cl_wide_kernel<bf16>;
-          if (ldsb > lds_set_w[0]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w[0] = ldsb; }
-          hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, (hipStream_t)stream, (const bf16*)x, (const bf16*)packed, (const bf16*)bias, (const bf16*)act_save, (bf16*)y, p);
-        } else {
-          auto kern = dconv_cl_wide_kernel<f16>;
-          if (ldsb > lds_set_w[1]) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w[1] = ldsb; }
-          hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, (hipStream_t)stream, (const f16*)x, (const f16*)packed, (const f16*)bias, (const f16*)act_save, (f16*)y, p);
-        }
+        hipStream_t st_ = (hipStream_t)stream;
+        dim3 grid(cdiv(W, 128), cdiv(Cout, rows), B * H);
+#define MV_WIDE(TT, PS_, MW_, NB_, CC_) do { \
+          auto kern = dconv_cl_wide_kernel<TT, PS_, MW_, NB_, CC_>; \
+          static size_t lds_set_w = 0; \
+          if (ldsb > lds_set_w) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w = ldsb; } \
+          hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, st_, (const TT*)x, (const TT*)packed, (const TT*)bias, (const TT*)act_save, (TT*)y, p); } while (0)
+#define MV_WIDE_R(TT, CC_) do { if (rows == 128) MV_WIDE(TT, 2, 2, 4, CC_); else if (rows == 64) MV_WIDE(TT, 4, 2, 2, CC_); else MV_WIDE(TT, 4, 1, 2, CC_); } while (0)
+#define MV_WIDE_T(TT) do { if (p.cchunk == 128) MV_WIDE_R(TT, 128); else if (p.cchunk == 64) MV_WIDE_R(TT, 64); else MV_WIDE_R(TT, 32); } while (0)
+        if (dtype == MV_BF16) MV_WIDE_T(bf16); else MV_WIDE_T(f16);
+#undef MV_WIDE_T
+#undef MV_WIDE_R
+#undef MV_WIDE
         MV_LAUNCH_CHECK();
         return MV_OK;
       }
     }
+    p.cchunk = Cin;
   }
   MV_DISPATCH(dtype, {
     hipStream_t s_ = (hipStream_t)stream;
