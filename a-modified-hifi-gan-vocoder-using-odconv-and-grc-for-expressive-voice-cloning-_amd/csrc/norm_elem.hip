@@ -161,10 +161,12 @@ __global__ __launch_bounds__(256) void mpd_fold_kernel(const T* __restrict__ x, 
 
 // ---------------------------------------------------------------- layout transposes (32x32 LDS tiles)
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn, int ldx, int ldy) {
-  // x [batch][R][ldx] (columns < Cn used) -> y [batch][Cn][ldy]; y columns R..ldy-1 are zero-filled (channel padding)
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn, int ldx, int ldy,
+                                                        long x_bs, long y_bs) {
+  // x [batch][R][ldx] (columns < Cn used) -> y [batch][Cn][ldy]; y columns R..ldy-1 are zero-filled (channel padding);
+  // x_bs / y_bs: elements between batches (y may be a window of a larger, pre-zeroed buffer)
   __shared__ float tile[32][33];
-  const long bx = (long)blockIdx.z * R * ldx, by = (long)blockIdx.z * Cn * ldy;
+  const long bx = (long)blockIdx.z * x_bs, by = (long)blockIdx.z * y_bs;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int i = ty; i < 32; i += 8)
@@ -324,11 +326,14 @@ extern "C" int mv_mpd_fold(const void* x, void* y, int64_t* index, long rows, in
   return MV_OK;
 }
 
-static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, int ldx, int ldy, int dtype, void* stream) {
+static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, int ldx, int ldy, int dtype, void* stream,
+                            long x_bs = -1, long y_bs = -1) {
   MV_CHECK_ARG(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0 && ldx >= Cn && ldy >= R && cdiv(ldy, 32) <= 65535);
+  if (x_bs < 0) x_bs = (long)R * ldx;
+  if (y_bs < 0) y_bs = (long)Cn * ldy;
   dim3 grid(cdiv(Cn, 32), cdiv(ldy, 32), batch);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
-                                        (T*)y, R, Cn, ldx, ldy));
+                                        (T*)y, R, Cn, ldx, ldy, x_bs, y_bs));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
@@ -341,6 +346,32 @@ extern "C" int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T_, int d
 extern "C" int mv_nct_to_ntc_pad(const void* x, void* y, int B, int C, int T_, int Cpad, int dtype, void* stream) {
   MV_CHECK_ARG(Cpad >= C);
   return transpose_launch(x, y, B, C, T_, T_, Cpad, dtype, stream);
+}
+// adjoint operator of ODConvTranspose1d with ks = 2*stride as a 2-tap stride-1 conv over rows of `stride` output steps:
+// out[k][c][r*Cout + o][qt] = w[k][c][o][qt*stride + r]   (w = kernels [K][Cin][Cout][ks])
+template <typename P>
+__global__ __launch_bounds__(256) void odconvT_adjoint_kernel(const P* __restrict__ w, P* __restrict__ out, long n, int Cout, int ks, int stride) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int qt = (int)(i % 2);
+    const long t1 = i / 2;
+    const int ro = (int)(t1 % ((long)stride * Cout));
+    const long kc = t1 / ((long)stride * Cout);
+    const int r = ro / Cout, o = ro - r * Cout;
+    out[i] = w[(kc * Cout + o) * ks + qt * stride + r];
+  }
+}
+extern "C" int mv_odconvT_adjoint_weights(const void* kernels, void* out, int K, int Cin, int Cout, int ks, int stride, int dtype,
+                                          void* stream) {
+  MV_CHECK_ARG(kernels && out && K > 0 && Cin > 0 && Cout > 0 && stride > 0 && ks == 2 * stride);
+  const long n = (long)K * Cin * Cout * ks;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(odconvT_adjoint_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)kernels,
+                                        (T*)out, n, Cout, ks, stride));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+extern "C" int mv_nct_to_ntc_window(const void* x, void* y, int B, int C, int T_, long y_batch_stride, int dtype, void* stream) {
+  MV_CHECK_ARG(y_batch_stride >= (long)T_ * C);
+  return transpose_launch(x, y, B, C, T_, T_, C, dtype, stream, -1, y_batch_stride);
 }
 extern "C" int mv_ntc_to_nct_crop(const void* x, void* y, int B, int C, int T_, int Cpad, int dtype, void* stream) {
   MV_CHECK_ARG(Cpad >= C);

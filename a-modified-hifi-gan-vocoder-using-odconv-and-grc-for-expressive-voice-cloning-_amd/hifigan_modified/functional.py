@@ -69,6 +69,7 @@ class _ODConv(Function):
         else:
             y = ops.conv1d(x, wk, wb, alpha, stride, padding, dilation, 1, act, slope)
         ctx.cfg = cfg
+        ctx.fused = fused
         ctx.save_for_backward(x, kernels, bias, att_w, att_b, alpha, pooled, y if act != N.ACT_NONE else None)
         return y
 
@@ -87,7 +88,11 @@ class _ODConv(Function):
         # such as the mel batch, whose gradient nobody consumes)
         gx = None
         if ctx.needs_input_grad[0]:
-            if transposed:
+            if transposed and ctx.fused is not None and x.dtype != torch.float32 and ctx.fused.dgrad_supported():
+                gx = ctx.fused.dgrad(g, alpha, Tin)      # the adjoint 2-tap ODConv on the fused MFMA kernel (None: tile too wide)
+            if gx is not None:
+                pass
+            elif transposed:
                 gx = ops.conv1d(g, wk, None, alpha, stride, padding, dilation, 1)
             else:
                 opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)

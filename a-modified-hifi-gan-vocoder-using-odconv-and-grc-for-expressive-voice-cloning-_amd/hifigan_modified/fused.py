@@ -147,6 +147,51 @@ class OdconvFused:
         self._packed[dtype] = (ver, buf)
         return buf
 
+    def dgrad_supported(self) -> bool:
+        """Data gradient on the fused kernel: transposed layers with kernel_size = 2*stride (every upsampler of the generator)."""
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        return bool(tr) and dil == 1 and ks == 2 * stride and self.mod.output_padding <= pad and cin % 16 == 0 and \
+            (stride * cout) % 8 == 0 and K <= 8
+
+    def packed_dgrad(self, dtype, device):
+        """The adjoint operator (2-tap stride-1 ODConv over rows of `stride` output steps), packed for mv_odconv_cl_fwd."""
+        w = self.mod.kernels
+        ver = (w._version, w.data_ptr(), ops.param_epoch())
+        hit = self._packed.get(("dgrad", dtype))
+        if hit is not None and hit[0] == ver and hit[1].device == device:
+            return hit[1]
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        wd = w.detach()
+        wd = wd if wd.is_contiguous() else wd.contiguous()
+        adj = torch.empty(K, cin, stride * cout, 2, device=device, dtype=wd.dtype)
+        P = lambda t: c_void_p(t.data_ptr())
+        N.call("mv_odconvT_adjoint_weights", P(wd), P(adj), K, cin, cout, ks, stride, ops._DT[wd.dtype], ops._stream())
+        nbytes = N.lib().mv_odconv_cl_packed_bytes(stride * cout, cin, 2, 1, 0, K, ops._DT[dtype])
+        if nbytes == 0:
+            raise RuntimeError("odconv_cl: unsupported adjoint geometry")
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        N.call("mv_odconv_cl_pack", P(adj), ops._DT[adj.dtype], P(buf), stride * cout, cin, 2, 1, 0, K, ops._DT[dtype], ops._stream())
+        self._packed[("dgrad", dtype)] = (ver, buf)
+        return buf
+
+    def dgrad(self, g, alpha, Tin):
+        """g [B,Cout,Tout] (NCT) -> gx [B,Cin,Tin] (NCT): the alpha-aggregated adjoint conv on the MFMA kernel."""
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        B, _, Tout = g.shape
+        rows = (Tin + 1) * stride
+        gp = torch.zeros(B, rows, cout, device=g.device, dtype=g.dtype)          # time-padded channels-last gradient
+        P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        N.call("mv_nct_to_ntc_window", P(g), c_void_p(gp.data_ptr() + pad * cout * g.element_size()), B, cout, Tout,
+               rows * cout, ops._dt(g), ops._stream())
+        gx_cl = torch.empty(B, Tin, cin, device=g.device, dtype=g.dtype)
+        rc = N.lib().mv_odconv_cl_fwd(P(gp), P(self.packed_dgrad(g.dtype, g.device)), None, P(alpha), None, None, None, None, 0,
+                                      P(gx_cl), None, B, stride * cout, Tin + 1, cin, Tin, 2, 1, 0, 1, 0, K, int(N.ACT_NONE), 0.1,
+                                      ops._dt(g), ops._stream())
+        if rc == -3:                         # MV_ERR_UNSUPPORTED: tile does not fit LDS (very wide adjoint input): the caller uses the generic HIP kernel
+            return None
+        N.check(rc, "mv_odconv_cl_fwd")
+        return ops.ntc_to_nct(gx_cl)
+
     def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
                    act=N.ACT_NONE, slope=0.1):
         m = self.mod

@@ -124,6 +124,14 @@ int mv_ntc_to_nct(const void* x, void* y, int B, int C, int T, int dtype, void* 
  * (20 and 60 channels, grc_lora.py:86-93) are padded to the 32-channel MFMA granule this way. */
 int mv_nct_to_ntc_pad(const void* x, void* y, int B, int C, int T, int Cpad, int dtype, void* stream);
 int mv_ntc_to_nct_crop(const void* x, void* y, int B, int C, int T, int Cpad, int dtype, void* stream);
+/* x [B][C][T] -> y [B][T][C] where consecutive batches of y are y_batch_stride elements apart: the transposed data lands in a
+ * window of a larger pre-zeroed channels-last buffer (time padding for the ODConvTranspose1d adjoint). */
+int mv_nct_to_ntc_window(const void* x, void* y, int B, int C, int T, long y_batch_stride, int dtype, void* stream);
+/* Data gradient of ODConvTranspose1d (odconv.py:172-205) with kernel_size = 2*stride as a stride-1 two-tap ODConv over rows
+ * of `stride` output steps: out [K][Cin][stride*Cout][2], out[k][c][r*Cout+o][q] = kernels[k][c][o][q*stride + r]; feed it
+ * to mv_odconv_cl_pack(transposed = 0) and run mv_odconv_cl_fwd on the (time-padded) output gradient. */
+int mv_odconvT_adjoint_weights(const void* kernels, void* out, int K, int Cin, int Cout, int ks, int stride, int dtype,
+                               void* stream);
 
 /* dtype conversion (fp32 <-> bf16/fp16) of n elements. */
 int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream);
