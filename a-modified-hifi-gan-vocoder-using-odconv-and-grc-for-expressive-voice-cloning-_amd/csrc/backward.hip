@@ -464,6 +464,16 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
   return MV_OK;
 }
 
+extern "C" int mv_odconv_wgrad_reduce(const float* gws, const void* w, const float* alpha, float* gw, float* galpha, int B, int K,
+                                      long nelem, int dtype, void* stream) {
+  MV_CHECK_ARG(gws && w && alpha && gw && galpha && B > 0 && K >= 1 && K <= 8 && nelem > 0);
+  const int epb = 256;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
+                                        sizeof(float) * B * K, (hipStream_t)stream, gws, (const T*)w, alpha, gw, galpha, B, K, nelem, epb));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
 extern "C" int mv_bias_grad(const void* gy, const float* alpha, const void* bias, float* rowsum_ws, float* gbias,
                             float* galpha, int B, int C, int T_, int K, long g_bs, long g_cs, int dtype, void* stream) {
   MV_CHECK_ARG(gy && rowsum_ws && gbias && B > 0 && C > 0 && T_ > 0 && K >= 1 && (K == 1 || alpha));

@@ -640,7 +640,10 @@ static int dtap_launch(const void* vec, const void* sc, float* gw, float* gb, in
 template <typename T, int TAPS_H, int TAPS_W, int WT>
 __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ g,
                                                           float* __restrict__ gws, float* __restrict__ gb, int B, int H, int W,
-                                                          int Cin, int Cout, int wsplit, int nchunks, int chunks_per_wg, int dil) {
+                                                          int Cin, int Cout, int wsplit, int nchunks, int chunks_per_wg, int dil,
+                                                          int xW, long sample_stride) {
+  // xW: rows per image line of x (= W, or W + 1 for the even-tap ODConv adjoint whose x operand is one row longer);
+  // sample_stride > 0: per-sample tiles - a workgroup's chunks all belong to sample (first chunk) / (H * wsplit)
   static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
   using M = Mma<T>;
   typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
   constexpr int GROWS = WT;
   constexpr int MAXHALO = TAPS_H == 1 ? 64 : TAPS_W - 1;    // (TAPS_W - 1) * dil, checked by the launcher
   constexpr int NLD = ((GROWS + TAPS_H * (WT + MAXHALO)) * 8 + 511) / 512;   // 16-byte pieces per thread per chunk
-  const int PW = (TAPS_W / 2) * dil;
+  const int PW = (TAPS_W & 1) ? (TAPS_W / 2) * dil : 0;    // even tap counts: offsets 0 .. TAPS_W-1 (no centring)
   const int XCOLS = WT + (TAPS_W - 1) * dil;
   const int ROWS = GROWS + TAPS_H * XCOLS;
   const int BUF = ROWS * RS;
@@ -703,8 +706,8 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
         const int rr = r - GROWS;
         const int pl = TAPS_H == 1 ? 0 : rr / XCOLS, col = rr - pl * XCOLS;
         const int hh = h - PH + pl, ww = w0 - PW + col;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
-          pre[i] = *reinterpret_cast<const u32x4*>(x + (((long)b * H + hh) * W + ww) * Cin + c0 + ch * 8);
+        if (hh >= 0 && hh < H && ww >= 0 && ww < xW && c0 + ch * 8 < Cin)
+          pre[i] = *reinterpret_cast<const u32x4*>(x + (((long)b * H + hh) * xW + ww) * Cin + c0 + ch * 8);
       }
     }
   };
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
     buf ^= 1;
   }
   if (do_gb && o0 + (tid & 63) < Cout) atomicAdd(gb + o0 + (tid & 63), bsum);
+  if (sample_stride > 0) gws += (long)(cbeg / (H * wsplit)) * sample_stride;
   // D[row = o (4*grp + r)][col = c (li)] -> gws[tap][o][c]
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -1165,7 +1169,8 @@ extern "C" size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int 
 }
 
 template <typename T, int TH, int TW_, int WT>
-static int dwgrad_launch(const void* x, const void* g, float* gws, float* gb, int B, int H, int W, int Cin, int Cout, int dil, hipStream_t s) {
+static int dwgrad_launch(const void* x, const void* g, float* gws, float* gb, int B, int H, int W, int Cin, int Cout, int dil, hipStream_t s,
+                         int xW = 0, long sample_stride = 0) {
   const int wsplit = cdiv(W, WT);
   const int halo = (TW_ - 1) * dil;
   if (halo > (TH == 1 ? 64 : TW_ - 1)) return MV_ERR_UNSUPPORTED;
@@ -1181,10 +1186,13 @@ static int dwgrad_launch(const void* x, const void* g, float* gws, float* gb, in
   static int target = 0;
   if (!target) { const char* e = getenv("MV_WGRAD_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
   int groups = target / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
-  const int cpw = (int)((nchunks + groups - 1) / groups);
+  int cpw = (int)((nchunks + groups - 1) / groups);
+  if (sample_stride > 0) cpw = H * wsplit;            // one workgroup per (tile, sample)
   groups = (int)((nchunks + cpw - 1) / cpw);
+  if (groups > 65535) return MV_ERR_UNSUPPORTED;
   dim3 grid(cdiv(Cin, 64), cdiv(Cout, 64), groups);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, gb, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw, dil);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, gb, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw, dil,
+                     xW > 0 ? xW : W, sample_stride);
   return MV_OK;
 }
 
@@ -1219,6 +1227,78 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
   const long total = (long)Cout * Cin * kh * kw;
   hipLaunchKernelGGL(dconv_wgrad_reorder_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),
                      0, s, workspace, gw, Cout * Cin, kh * kw);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ ODConvTranspose1d bank gradients
+// gW[k][c][o][j] = sum_b alpha[b,k] sum_t x[b,t,c] g[b, t*s + j - p, o]   and   d alpha[b,k] = <per-sample gradient, W[k]>
+// (odconv.py:172-205, ks = 2*stride).  With the time-padded gradient gp [B][Tin+1][s*Cout] (row q, channel r*Cout+o holds
+// g[q*s + r - p][o]) the per-sample gradient is the two-tap weight gradient  tile[b][q][c][(r,o)] = sum_t x[t][c] gp[t+q][(r,o)]:
+// one MFMA GEMM per sample (dconv_wgrad_kernel with per-sample output), then the existing alpha-chain reduction against the
+// banks in the same tap-major layout, and the inverse layout map back to [K][Cin][Cout][ks].
+template <typename T>
+__global__ __launch_bounds__(256) void odconvT_tapmajor_kernel(const T* __restrict__ w, T* __restrict__ out, long n, int Cin, int Cout, int ks,
+                                                               int stride) {
+  // out[k][q][c][r*Cout + o] = w[k][c][o][q*stride + r]
+  const long sc = (long)stride * Cout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ro = (int)(i % sc);
+    const long t1 = i / sc;
+    const int c = (int)(t1 % Cin);
+    const long kq = t1 / Cin;
+    const int q = (int)(kq % 2);
+    const long k = kq / 2;
+    const int r = ro / Cout, o = ro - r * Cout;
+    out[i] = w[((k * Cin + c) * Cout + o) * ks + q * stride + r];
+  }
+}
+__global__ __launch_bounds__(256) void odconvT_tapmajor_inv_kernel(const float* __restrict__ gtm, float* __restrict__ gw, long n, int Cin, int Cout,
+                                                                   int ks, int stride) {
+  // gw[k][c][o][j] = gtm[k][j / stride][c][(j % stride)*Cout + o]
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % ks);
+    const long t1 = i / ks;
+    const int o = (int)(t1 % Cout);
+    const long kc = t1 / Cout;
+    const int c = (int)(kc % Cin);
+    const long k = kc / Cin;
+    const int q = j / stride, r = j - q * stride;
+    gw[i] = gtm[((k * 2 + q) * Cin + c) * ((long)stride * Cout) + (long)r * Cout + o];
+  }
+}
+
+extern "C" int mv_odconv_wgrad_reduce(const float* gws, const void* w, const float* alpha, float* gw, float* galpha, int B, int K,
+                                      long nelem, int dtype, void* stream);
+
+extern "C" size_t mv_odconvT_wgrad_workspace_bytes(int B, int Cin, int Cout, int ks, int K, int dtype) {
+  const size_t n = (size_t)Cin * Cout * ks;                    // elements of one bank == one per-sample tile
+  return sizeof(float) * n * B + (dtype == MV_F32 ? 4 : 2) * n * K + sizeof(float) * n * K + 1024;
+}
+
+extern "C" int mv_odconvT_wgrad_mfma(const void* x_cl, const void* gp, const void* w, const float* alpha, float* gw, float* galpha,
+                                     void* workspace, int B, int Tin, int Cin, int Cout, int ks, int stride, int K, int dtype,
+                                     void* stream) {
+  MV_CHECK_ARG(x_cl && gp && w && alpha && gw && galpha && workspace && B > 0 && Tin > 0 && K >= 1 && K <= 8 && ks == 2 * stride);
+  MV_CHECK_ARG(Cin % 8 == 0 && (stride * Cout) % 8 == 0 && ((uintptr_t)x_cl & 15) == 0 && ((uintptr_t)gp & 15) == 0);
+  if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)Cin * Cout * ks;
+  float* tiles = (float*)workspace;                                           // [B][2][Cin][s*Cout]
+  char* wtm = (char*)(tiles + n * B);                                         // [K][2][Cin][s*Cout] in `dtype`
+  float* gtm = (float*)(wtm + ((size_t)2 * n * K + 255) / 256 * 256);         // [K][2][Cin][s*Cout] fp32
+  hipMemsetAsync(tiles, 0, sizeof(float) * (size_t)n * B, s);
+  // "g" operand = x (rows = input channels), "x" operand = padded gradient rows (columns = (r, o)), taps q = 0, 1
+  int rc;
+  if (dtype == MV_BF16) rc = dwgrad_launch<bf16, 1, 2, 128>(gp, x_cl, tiles, nullptr, B, 1, Tin, stride * Cout, Cin, 1, s, Tin + 1, n);
+  else rc = dwgrad_launch<f16, 1, 2, 128>(gp, x_cl, tiles, nullptr, B, 1, Tin, stride * Cout, Cin, 1, s, Tin + 1, n);
+  if (rc != MV_OK) return rc;
+  const int g1 = (int)((n * K + 255) / 256 > 4096 ? 4096 : (n * K + 255) / 256);
+  if (dtype == MV_BF16) hipLaunchKernelGGL(odconvT_tapmajor_kernel<bf16>, dim3(g1), dim3(256), 0, s, (const bf16*)w, (bf16*)wtm, n * K, Cin, Cout, ks, stride);
+  else hipLaunchKernelGGL(odconvT_tapmajor_kernel<f16>, dim3(g1), dim3(256), 0, s, (const f16*)w, (f16*)wtm, n * K, Cin, Cout, ks, stride);
+  rc = mv_odconv_wgrad_reduce(tiles, wtm, alpha, gtm, galpha, B, K, n, dtype, stream);
+  if (rc != MV_OK) return rc;
+  hipLaunchKernelGGL(odconvT_tapmajor_inv_kernel, dim3(g1), dim3(256), 0, s, gtm, gw, n * K, Cin, Cout, ks, stride);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -87,9 +87,11 @@ class _ODConv(Function):
         # data gradient: the adjoint convolution with the same (alpha-aggregated) kernels (skipped for a leaf input
         # such as the mel batch, whose gradient nobody consumes)
         gx = None
+        mfma = transposed and ctx.fused is not None and x.dtype != torch.float32 and ctx.fused.dgrad_supported()
+        gp = ctx.fused.pad_grad(g, Tin) if mfma else None      # time-padded channels-last gradient shared by both adjoint ops
         if ctx.needs_input_grad[0]:
-            if transposed and ctx.fused is not None and x.dtype != torch.float32 and ctx.fused.dgrad_supported():
-                gx = ctx.fused.dgrad(g, alpha, Tin)      # the adjoint 2-tap ODConv on the fused MFMA kernel (None: tile too wide)
+            if mfma:
+                gx = ctx.fused.dgrad(gp, alpha, Tin)     # the adjoint 2-tap ODConv on the fused MFMA kernel (None: tile too wide)
             if gx is not None:
                 pass
             elif transposed:
@@ -98,7 +100,10 @@ class _ODConv(Function):
                 opad = Tin - ((Tout - 1) * stride - 2 * padding + dilation * (ks - 1) + 1)
                 gx = ops.conv_transpose1d(g, wk, None, alpha, stride, padding, opad, dilation)
         # kernel-bank gradient + d alpha = <per-sample wgrad, W_k>
-        if transposed:   # same kernel with the roles of input and output-gradient swapped
+        res = ctx.fused.wgrad(ops.nct_to_ntc(x), gp, wk, alpha) if mfma else None
+        if res is not None:
+            gw, galpha = res
+        elif transposed:   # same kernel with the roles of input and output-gradient swapped
             gw, galpha = ops.conv1d_wgrad(g, x, wk, alpha, ks, stride, padding, dilation)
         else:
             gw, galpha = ops.conv1d_wgrad(x, g, wk, alpha, ks, stride, padding, dilation)

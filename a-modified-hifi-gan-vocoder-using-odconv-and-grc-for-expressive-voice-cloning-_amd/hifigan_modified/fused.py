@@ -174,23 +174,46 @@ class OdconvFused:
         self._packed[("dgrad", dtype)] = (ver, buf)
         return buf
 
-    def dgrad(self, g, alpha, Tin):
-        """g [B,Cout,Tout] (NCT) -> gx [B,Cin,Tin] (NCT): the alpha-aggregated adjoint conv on the MFMA kernel."""
+    def pad_grad(self, g, Tin):
+        """g [B,Cout,Tout] (NCT) -> the time-padded channels-last gradient [B][(Tin+1)*stride][Cout]: row q*stride + r holds
+        g[:, :, q*stride + r - pad] (zeros outside), i.e. viewed as [B][Tin+1][stride*Cout] it is the input of the adjoint ops."""
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         B, _, Tout = g.shape
         rows = (Tin + 1) * stride
-        gp = torch.zeros(B, rows, cout, device=g.device, dtype=g.dtype)          # time-padded channels-last gradient
-        P = lambda t: None if t is None else c_void_p(t.data_ptr())
-        N.call("mv_nct_to_ntc_window", P(g), c_void_p(gp.data_ptr() + pad * cout * g.element_size()), B, cout, Tout,
+        gp = torch.zeros(B, rows, cout, device=g.device, dtype=g.dtype)
+        N.call("mv_nct_to_ntc_window", c_void_p(g.data_ptr()), c_void_p(gp.data_ptr() + pad * cout * g.element_size()), B, cout, Tout,
                rows * cout, ops._dt(g), ops._stream())
-        gx_cl = torch.empty(B, Tin, cin, device=g.device, dtype=g.dtype)
-        rc = N.lib().mv_odconv_cl_fwd(P(gp), P(self.packed_dgrad(g.dtype, g.device)), None, P(alpha), None, None, None, None, 0,
+        return gp
+
+    def dgrad(self, gp, alpha, Tin):
+        """padded gradient -> gx [B,Cin,Tin] (NCT): the alpha-aggregated adjoint conv on the MFMA kernel (None: tile too wide)."""
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        B = gp.shape[0]
+        P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        gx_cl = torch.empty(B, Tin, cin, device=gp.device, dtype=gp.dtype)
+        rc = N.lib().mv_odconv_cl_fwd(P(gp), P(self.packed_dgrad(gp.dtype, gp.device)), None, P(alpha), None, None, None, None, 0,
                                       P(gx_cl), None, B, stride * cout, Tin + 1, cin, Tin, 2, 1, 0, 1, 0, K, int(N.ACT_NONE), 0.1,
-                                      ops._dt(g), ops._stream())
+                                      ops._dt(gp), ops._stream())
         if rc == -3:                         # MV_ERR_UNSUPPORTED: tile does not fit LDS (very wide adjoint input): the caller uses the generic HIP kernel
             return None
         N.check(rc, "mv_odconv_cl_fwd")
         return ops.ntc_to_nct(gx_cl)
+
+    def wgrad(self, x_cl, gp, wk, alpha):
+        """Bank gradients gw fp32 [K,Cin,Cout,ks] and d alpha fp32 [B,K] on MFMA (per-sample two-tap weight-gradient GEMMs +
+        the alpha-chain reduction); None when the shape is outside the kernel's envelope."""
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        B, Tin, _ = x_cl.shape
+        P = lambda t: c_void_p(t.data_ptr())
+        gw = torch.empty(K, cin, cout, ks, device=x_cl.device, dtype=torch.float32)
+        galpha = torch.zeros(B, K, device=x_cl.device, dtype=torch.float32)
+        ws = torch.empty(N.lib().mv_odconvT_wgrad_workspace_bytes(B, cin, cout, ks, K, ops._dt(x_cl)), dtype=torch.uint8, device=x_cl.device)
+        rc = N.lib().mv_odconvT_wgrad_mfma(P(x_cl), P(gp), P(wk), P(alpha), P(gw), P(galpha), P(ws), B, Tin, cin, cout, ks, stride, K,
+                                           ops._dt(x_cl), ops._stream())
+        if rc == -3:
+            return None
+        N.check(rc, "mv_odconvT_wgrad_mfma")
+        return gw, galpha
 
     def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
                    act=N.ACT_NONE, slope=0.1):

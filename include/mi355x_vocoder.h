@@ -132,6 +132,16 @@ int mv_nct_to_ntc_window(const void* x, void* y, int B, int C, int T, long y_bat
  * to mv_odconv_cl_pack(transposed = 0) and run mv_odconv_cl_fwd on the (time-padded) output gradient. */
 int mv_odconvT_adjoint_weights(const void* kernels, void* out, int K, int Cin, int Cout, int ks, int stride, int dtype,
                                void* stream);
+/* Bank gradients of ODConvTranspose1d (odconv.py:172-205, kernel_size = 2*stride) on MFMA: x_cl [B][Tin][Cin] (the layer
+ * input, channels-last), gp = the time-padded output gradient [B][Tin+1][stride*Cout] (row q, channel r*Cout+o = g[q*stride+r-pad][o]),
+ * w = kernels [K][Cin][Cout][ks] in `dtype`, alpha fp32 [B][K].  gw fp32 [K][Cin][Cout][ks] = sum_b alpha[b,k] * (per-sample
+ * gradient); galpha fp32 [B][K] += <per-sample gradient, W[k]>.  workspace: mv_odconvT_wgrad_workspace_bytes.
+ * mv_odconv_wgrad_reduce is the alpha-chain reduction alone (per-sample tiles and banks in any common layout). */
+size_t mv_odconvT_wgrad_workspace_bytes(int B, int Cin, int Cout, int ks, int K, int dtype);
+int mv_odconvT_wgrad_mfma(const void* x_cl, const void* gp, const void* w, const float* alpha, float* gw, float* galpha,
+                          void* workspace, int B, int Tin, int Cin, int Cout, int ks, int stride, int K, int dtype, void* stream);
+int mv_odconv_wgrad_reduce(const float* gws, const void* w, const float* alpha, float* gw, float* galpha, int B, int K,
+                           long nelem, int dtype, void* stream);
 
 /* dtype conversion (fp32 <-> bf16/fp16) of n elements. */
 int mv_cast(const void* x, int src_dtype, void* y, int dst_dtype, long n, void* stream);

@@ -303,8 +303,9 @@ def test_conv1d_mfma_route_vs_fp64(H, dtype, cin, cout, ks, dil, T):
 @pytest.mark.parametrize("cin,cout,ks,stride,pad,T", [(64, 64, 4, 2, 1, 50), (128, 64, 4, 2, 1, 33), (256, 128, 16, 8, 4, 20), (64, 32, 8, 4, 2, 40)])
 def test_odconv_transpose_mfma_data_gradient_vs_fp64(H, dtype, cin, cout, ks, stride, pad, T):
     """16-bit ODConvTranspose1d (odconv.py:172-205): the data gradient runs on the fused MFMA kernel as the adjoint two-tap
-    ODConv over rows of `stride` output steps (kernel_size = 2*stride).  Checked against an fp64 CPU evaluation of the
-    reference arithmetic on the same 16-bit-rounded parameters and input: x.grad (which also carries the attention path)."""
+    ODConv over rows of `stride` output steps (kernel_size = 2*stride), the bank gradients as per-sample two-tap MFMA
+    weight-gradient GEMMs + the alpha-chain reduction.  Checked against an fp64 CPU evaluation of the reference arithmetic
+    on the same 16-bit-rounded parameters and input: x.grad, kernels.grad, bias.grad and the attention-head gradients."""
     import torch.nn.functional as F
     torch.manual_seed(0)
     m = H.ODConvTranspose1d(cin, cout, ks, stride=stride, padding=pad)
@@ -315,9 +316,9 @@ def test_odconv_transpose_mfma_data_gradient_vs_fp64(H, dtype, cin, cout, ks, st
     x = torch.randn(3, cin, T).to(dtype)
     # fp64 reference: alpha = softmax(Wa mean_t x + ba); y = sum_k alpha_k convT(x, W_k) + alpha_k b_k
     xr = x.double().requires_grad_(True)
-    Wk, bk = m.kernels.detach().double(), m.bias.detach().double()
     att = m.kernel_attention[1]
-    a = torch.softmax(F.conv1d(xr.mean(2, keepdim=True), att.weight.detach().double(), att.bias.detach().double()).squeeze(-1), dim=1)
+    Wk, bk, Wa, ba = (t.detach().double().requires_grad_(True) for t in (m.kernels, m.bias, att.weight, att.bias))
+    a = torch.softmax(F.conv1d(xr.mean(2, keepdim=True), Wa, ba).squeeze(-1), dim=1)
     yr = sum(a[:, k].view(-1, 1, 1) * F.conv_transpose1d(xr, Wk[k], bk[k], stride=stride, padding=pad) for k in range(Wk.shape[0]))
     torch.manual_seed(2)
     r = torch.randn_like(yr)
@@ -332,3 +333,8 @@ def test_odconv_transpose_mfma_data_gradient_vs_fp64(H, dtype, cin, cout, ks, st
     eps = 3e-2 if dtype == torch.bfloat16 else 4e-3
     assert O.rel_l2(y.detach().cpu(), yr.detach()) < eps
     assert O.rel_l2(xd.grad.cpu(), xr.grad) < eps
+    # bank gradients and the attention chain (d alpha = <per-sample gradient, W_k>) from the MFMA per-sample GEMMs
+    assert O.rel_l2(md.kernels.grad.cpu(), Wk.grad) < eps
+    assert O.rel_l2(md.bias.grad.cpu(), bk.grad) < eps
+    assert O.rel_l2(md.kernel_attention[1].weight.grad.cpu(), Wa.grad) < 3 * eps
+    assert O.rel_l2(md.kernel_attention[1].bias.grad.cpu(), ba.grad) < 3 * eps
