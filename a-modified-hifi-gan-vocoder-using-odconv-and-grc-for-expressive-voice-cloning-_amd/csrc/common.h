@@ -84,4 +84,6 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
   }
 
 #define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
+// runtime calls that are not kernel launches: propagate the hipError_t as the entry point's (positive) return code
+#define MV_HIP(call) do { const hipError_t mv_e_ = (call); if (mv_e_ != hipSuccess) return (int)mv_e_; } while (0)
 #define MV_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
