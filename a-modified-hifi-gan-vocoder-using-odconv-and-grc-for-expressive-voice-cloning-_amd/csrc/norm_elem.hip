@@ -42,6 +42,76 @@ __global__ __launch_bounds__(256) void odconv_attn_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------- generator prologue (one launch, one workgroup per sample)
+// Everything the channels-last generator needs before its first conv, fused: (1) input_proj's ODConv attention
+// alpha = softmax(Wa . mean_t mel + ba) (odconv.py:36-40), (2) mel [C][T] -> channels-last [T][C], (3) the FiLM projection
+// proj = W . cond + b with cond = cat(spk, emo) truncated / zero-padded to the projection's input width (grc_lora.py:82-105),
+// (4) zeroing of this sample's share of the pooled-sum buffers the upsamplers accumulate into.
+template <typename T>
+__global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
+                                                           const T* __restrict__ spk, const T* __restrict__ emo, const T* __restrict__ film_w,
+                                                           const T* __restrict__ film_b, float* __restrict__ alpha, T* __restrict__ x_cl,
+                                                           T* __restrict__ film_proj, float* __restrict__ zero_buf, long zero_n, int C,
+                                                           int Tn, int K, int ds, int de, int cond_dim, int F2) {
+  extern __shared__ float sm[];          // [C*Tn] the sample, [C] means, [K] logits, [cond_dim] condition
+  float* xs = sm;
+  float* mean = xs + C * Tn;
+  float* logit = mean + C;
+  float* cond = logit + K;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const T* xb = mel + (long)b * C * Tn;
+  for (int i = tid; i < C * Tn; i += 256) xs[i] = ld<T>(xb + i);
+  for (int i = tid; i < cond_dim; i += 256) {
+    float v = 0.f;
+    if (i < ds) v = ld<T>(spk + (long)b * ds + i);
+    else if (i < ds + de) v = ld<T>(emo + (long)b * de + (i - ds));
+    cond[i] = v;
+  }
+  // this sample's slice of the buffers that must be zero before the upsamplers run
+  {
+    const long per = (zero_n + gridDim.x - 1) / gridDim.x, z0 = (long)b * per;
+    const long z1 = z0 + per < zero_n ? z0 + per : zero_n;
+    for (long i = z0 + tid; i < z1; i += 256) zero_buf[i] = 0.f;
+  }
+  __syncthreads();
+  // channels-last copy
+  T* yb = x_cl + (long)b * Tn * C;
+  for (int i = tid; i < C * Tn; i += 256) {
+    const int t = i / C, c = i - t * C;
+    st<T>(yb + i, xs[c * Tn + t]);
+  }
+  // attention
+  const float inv = 1.f / (float)Tn;
+  for (int c = wid; c < C; c += 4) {
+    float a = 0.f;
+    for (int t = lane; t < Tn; t += 64) a += xs[c * Tn + t];
+    a = wave_sum(a);
+    if (lane == 0) mean[c] = a * inv;
+  }
+  // FiLM projection: wave per output row
+  if (film_proj)
+    for (int j = wid; j < F2; j += 4) {
+      float a = 0.f;
+      for (int i = lane; i < cond_dim; i += 64) a += ld<T>(film_w + (long)j * cond_dim + i) * cond[i];
+      a = wave_sum(a);
+      if (lane == 0) st<T>(film_proj + (long)b * F2 + j, a + (film_b ? ld<T>(film_b + j) : 0.f));
+    }
+  __syncthreads();
+  for (int k = wid; k < K; k += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += ld<T>(att_w + (long)k * C + c) * mean[c];
+    a = wave_sum(a);
+    if (lane == 0) logit[k] = a + (att_b ? ld<T>(att_b + k) : 0.f);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = -INFINITY, den = 0.f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logit[k]);
+    for (int k = 0; k < K; ++k) den += expf(logit[k] - m);
+    for (int k = 0; k < K; ++k) alpha[(long)b * K + k] = expf(logit[k] - m) / den;
+  }
+}
+
 // ---------------------------------------------------------------- GroupNorm
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ mean,
@@ -251,6 +321,21 @@ extern "C" int mv_odconv_attn_fwd(const void* x, const void* w, const void* bias
   MV_CHECK_ARG(lds <= 64 * 1024);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_attn_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream,
                                         (const T*)x, (const T*)w, (const T*)bias, alpha, pooled, C, T_, K));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo,
+                               const void* film_w, const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf,
+                               long zero_n, int B, int C, int T_, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream) {
+  MV_CHECK_ARG(mel && att_w && alpha && x_cl && B > 0 && C > 0 && T_ > 0 && K > 0 && K <= 64 && ds >= 0 && de >= 0 && zero_n >= 0);
+  MV_CHECK_ARG((ds == 0 || spk) && (de == 0 || emo) && (!film_proj || (film_w && cond_dim > 0 && F2 > 0)) && (zero_n == 0 || zero_buf));
+  const size_t lds = sizeof(float) * ((size_t)C * T_ + C + K + (film_proj ? cond_dim : 0));
+  if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;   // long inputs: the caller issues the separate launches
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)mel,
+                                        (const T*)att_w, (const T*)att_b, (const T*)spk, (const T*)emo, (const T*)film_w,
+                                        (const T*)film_b, alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, C, T_, K, ds, de,
+                                        film_proj ? cond_dim : 0, F2));
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

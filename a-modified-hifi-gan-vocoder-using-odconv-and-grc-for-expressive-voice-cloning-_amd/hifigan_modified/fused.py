@@ -274,17 +274,36 @@ class GeneratorFused:
         mel = mel if mel.is_contiguous() else mel.contiguous()
         att = g.input_proj.kernel_attention[1]
         K0, C0 = att.weight.shape[0], att.weight.shape[1]
-        alpha0 = ops.odconv_attn(mel, cache.get(att.weight, dt).view(K0, C0), cache.get(att.bias, dt))
-        x = ops.nct_to_ntc(mel)
-        film_proj, F = None, 0
-        cond = g.final_film.condition(speaker_emb, emotion_emb)
-        if cond is not None:
-            fp = g.final_film.condition_projection
-            film_proj = ops.linear(ops.cast(cond, dt), cache.get(fp.weight, dt), cache.get(fp.bias, dt))
-            F = g.final_film.feature_dim
         chans = [u.mod.in_channels for u in self.ups]
-        # pooled channel sums handed from each producer to its consumer: dense [B][Cin] views of ONE zero fill
-        flat = torch.zeros(sum(B * c for c in chans), device=mel.device, dtype=torch.float32)
+        # pooled channel sums handed from each producer to its consumer: dense [B][Cin] views of ONE buffer
+        nflat = sum(B * c for c in chans)
+        P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        has_cond = speaker_emb is not None or emotion_emb is not None
+        fp = g.final_film.condition_projection
+        F = g.final_film.feature_dim if has_cond else 0
+        # one launch: attention of input_proj, the channels-last copy of the mel, the FiLM projection, the zero fill
+        flat = torch.empty(nflat, device=mel.device, dtype=torch.float32)
+        alpha0 = torch.empty(B, K0, device=mel.device, dtype=torch.float32)
+        x = torch.empty(B, mel.shape[2], mel.shape[1], device=mel.device, dtype=dt)
+        film_proj = torch.empty(B, 2 * F, device=mel.device, dtype=dt) if has_cond else None
+        spk = None if speaker_emb is None else ops.cast(speaker_emb, dt).contiguous()
+        emo = None if emotion_emb is None else ops.cast(emotion_emb, dt).contiguous()
+        rc = N.lib().mv_gen_prologue(P(mel), P(cache.get(att.weight, dt)), P(cache.get(att.bias, dt)), P(spk), P(emo),
+                                     P(cache.get(fp.weight, dt)) if has_cond else None, P(cache.get(fp.bias, dt)) if has_cond else None,
+                                     P(alpha0), P(x), P(film_proj), P(flat), nflat, B, mel.shape[1], mel.shape[2], K0,
+                                     0 if spk is None else spk.shape[1], 0 if emo is None else emo.shape[1], fp.in_features, 2 * F,
+                                     ops._dt(mel), ops._stream())
+        if rc == -3:    # MV_ERR_UNSUPPORTED: a long utterance does not fit one workgroup's LDS - separate launches
+            alpha0 = ops.odconv_attn(mel, cache.get(att.weight, dt).view(K0, C0), cache.get(att.bias, dt))
+            x = ops.nct_to_ntc(mel)
+            film_proj = None
+            cond = g.final_film.condition(speaker_emb, emotion_emb)
+            if cond is not None:
+                film_proj = ops.linear(ops.cast(cond, dt), cache.get(fp.weight, dt), cache.get(fp.bias, dt))
+            flat = torch.zeros(nflat, device=mel.device, dtype=torch.float32)
+        else:
+            N.check(rc, "mv_gen_prologue")
+        cond = film_proj
         views, o = [], 0
         for c in chans:
             views.append(flat[o:o + B * c].view(B, c))

@@ -194,6 +194,13 @@ int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const 
                      const void* att_w, const void* att_b, const void* film_proj, int film_F, void* y,
                      float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad,
                      int dil, int transposed, int K, int act, float slope, int dtype, void* stream);
+/* Generator prologue in one launch (one workgroup per sample): input_proj's attention alpha fp32 [B][K] (odconv.py:36-40),
+ * mel [B][C][T] -> x_cl [B][T][C], the FiLM projection film_proj [B][F2] = W cond + b with cond = cat(spk [B][ds], emo [B][de])
+ * truncated / zero-padded to cond_dim (grc_lora.py:82-105; film_proj NULL = no conditioning), and zeroing of zero_buf[0..zero_n)
+ * (the pooled-sum buffers of the upsamplers).  MV_ERR_UNSUPPORTED when one sample does not fit LDS. */
+int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo, const void* film_w,
+                    const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf, long zero_n, int B, int C,
+                    int T, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream);
 
 /* Output projection, channels-last in, waveform out.   replaces SURVEY.md §A item 4: nn.Conv1d(C,1,ks,padding=ks/2) + torch.tanh
  *   x [B][T][C] -> y [B][1][T].  wt = mv_conv_out_pack(weight [1,C,ks]) (fp32 [ks][C]).  C must be 64, ks odd. */
