@@ -167,9 +167,10 @@ def main():
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "mv::mrf_kernel (fused MRF block = 3 pass launches)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per block from the PMC passes committed in profiles/r01_pmc_inference_bf16.csv (separate --pmc runs,
-                # FETCH_SIZE doubled per the gfx950 correction): 3 x 33.3 MB read + 32.3 MB written, at this exact workload
-                "traffic": 132_300_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
+                # HBM bytes per block from the PMC passes committed in profiles/r01_pmc_traffic_bf16.csv (separate --pmc FETCH_SIZE /
+                # WRITE_SIZE runs of this command, FETCH_SIZE doubled per the gfx950 correction): 34.3 + 34.6 + 38.5 MB read,
+                # 37.1 MB written, at this exact workload
+                "traffic": 144_500_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
                 "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic"}
 
