@@ -67,6 +67,15 @@ def param_epoch():
     return _EPOCH[0]
 
 
+_SHADOW_OWNERS = {}     # id(parameter) -> weakref(flat-arena optimizer holding a 16-bit shadow of it)
+
+
+def register_shadow_owner(opt, params):
+    ref = weakref.ref(opt)
+    for p in params:
+        _SHADOW_OWNERS[id(p)] = ref
+
+
 class _ParamCache:
     """Casts of parameters to the activation dtype.  An entry is valid only for the very same tensor
     object (weak reference - ids are recycled once a module is freed) at the same ``_version``, so an
@@ -80,6 +89,15 @@ class _ParamCache:
             return None
         if p.dtype == dtype and p.is_contiguous():
             return p.detach()
+        owner = _SHADOW_OWNERS.get(id(p))     # flat-arena optimizer: one cast launch per step covers every parameter
+        if owner is not None and dtype != torch.float32:
+            opt = owner()
+            if opt is None:
+                _SHADOW_OWNERS.pop(id(p), None)
+            else:
+                v = opt.shadow_view(p, dtype)      # validates that id(p) still names the very parameter it registered
+                if v is not None:
+                    return v
         key = (id(p), dtype)
         hit = self._d.get(key)
         if hit is not None and hit[0]() is p and hit[1] == (p._version, _EPOCH[0]) and hit[2].device == p.device:

@@ -32,7 +32,7 @@ class FlatAdamW:
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
+            off += (p.numel() + 7) // 8 * 8          # keep every view (and its 16-bit shadow) 16-byte aligned
         self.numel = off
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -44,6 +44,12 @@ class FlatAdamW:
                 ops.copy_rows(p.detach().reshape(1, 1, -1), view.view(1, 1, -1))
                 p.data = view
         self.step_count = 0
+        # 16-bit shadows of the arena (one per activation dtype in use): refreshed by ONE cast launch per optimizer step, so
+        # the ~200 per-parameter casts of a training step disappear; ops._ParamCache hands out views of them
+        self._shadows = {}
+        self._shadow_state = None            # (param epoch, per-parameter _version list) the shadows correspond to
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        ops.register_shadow_owner(self, self.params)
         self._descs = np.zeros(len(self.params), dtype=_DESC)
         self._descs["dst_off"] = self.offsets
         self._descs["n"] = [p.numel() for p in self.params]
@@ -80,6 +86,30 @@ class FlatAdamW:
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                int(self.step_count), float(grad_scale), ops._stream())
         ops.bump_param_epoch()           # in-place arena update: cached casts / packed weights must refresh
+        self._refresh_shadows()
+
+    def _refresh_shadows(self):
+        for dt, sh in self._shadows.items():
+            N.call("mv_cast", c_void_p(self.flat_p.data_ptr()), N.MV_F32, c_void_p(sh.data_ptr()), ops._DT[dt], self.numel, ops._stream())
+        self._shadow_state = (ops.param_epoch(), [p._version for p in self.params])
+
+    def shadow_view(self, p, dtype):
+        """The `dtype` copy of parameter p as a view of the arena's shadow, or None when p was modified behind the arena's back
+        (load_state_dict / copy_ since the last refresh) - the caller then casts it the slow way."""
+        i = self._index.get(id(p))
+        if i is None or self.params[i] is not p:
+            return None
+        st = self._shadow_state
+        if dtype not in self._shadows or st is None or st[0] != ops.param_epoch() or st[1][i] != p._version:
+            if st is not None and st[0] == ops.param_epoch() and st[1][i] != p._version:
+                return None
+            if dtype not in self._shadows:
+                self._shadows[dtype] = torch.empty(self.numel, device=self.flat_p.device, dtype=dtype)
+            self._refresh_shadows()
+            if self._shadow_state[1][i] != p._version:
+                return None
+        o = self.offsets[i]
+        return self._shadows[dtype][o:o + p.numel()].view(p.shape)
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
