@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------- GroupNorm
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4v;
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ mean,
                                                        float* __restrict__ rstd, int C, int Tn, int G, float eps,
@@ -122,18 +123,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   const int cg = C / G;
   const T* xb = x + (long)b * x_bs + (long)(g * cg) * x_cs;
   const long n = (long)cg * Tn;
-  // two-pass (mean, then centred second moment) for accuracy: the data is L2-resident on the second pass
+  // two-pass (mean, then centred second moment) for accuracy: the data is L2-resident on the second pass.
+  // Rows are walked channel by channel (no per-element division); 16-bit rows that allow it are read 16 bytes at a time.
+  constexpr int EPV = 16 / sizeof(T);
+  const bool vec = sizeof(T) == 2 && Tn % EPV == 0 && x_cs % EPV == 0 && x_bs % EPV == 0 && ((uintptr_t)x & 15) == 0;
   float s = 0.f;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
-    const int c = (int)(i / Tn), t = (int)(i % Tn);
-    s += ld<T>(xb + (long)c * x_cs + t);
+  for (int c = 0; c < cg; ++c) {
+    const T* row = xb + (long)c * x_cs;
+    if (vec) {
+      for (int t = threadIdx.x * EPV; t < Tn; t += blockDim.x * EPV) {
+        alignas(16) T tmp[EPV];
+        *reinterpret_cast<u32x4v*>(tmp) = *reinterpret_cast<const u32x4v*>(row + t);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) s += ld<T>(tmp + e);
+      }
+    } else {
+      for (int t = threadIdx.x; t < Tn; t += blockDim.x) s += ld<T>(row + t);
+    }
   }
   const float mu = block_sum(s, red) / (float)n;
   float q = 0.f;
-  for (long i = threadIdx.x; i < n; i += blockDim.x) {
-    const int c = (int)(i / Tn), t = (int)(i % Tn);
-    const float d = ld<T>(xb + (long)c * x_cs + t) - mu;
-    q += d * d;
+  for (int c = 0; c < cg; ++c) {
+    const T* row = xb + (long)c * x_cs;
+    if (vec) {
+      for (int t = threadIdx.x * EPV; t < Tn; t += blockDim.x * EPV) {
+        alignas(16) T tmp[EPV];
+        *reinterpret_cast<u32x4v*>(tmp) = *reinterpret_cast<const u32x4v*>(row + t);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { const float d = ld<T>(tmp + e) - mu; q += d * d; }
+      }
+    } else {
+      for (int t = threadIdx.x; t < Tn; t += blockDim.x) { const float d = ld<T>(row + t) - mu; q += d * d; }
+    }
   }
   const float var = block_sum(q, red) / (float)n;
   if (threadIdx.x == 0) {
