@@ -431,21 +431,29 @@ __global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ 
     const bool ok = pos < npos;
     const long pc = ok ? pos : npos - 1;
     const int w = (int)(pc % W), h = (int)((pc / W) % H);
-    // B[k = tap = 8g + j][col]: gy at the position this tap reaches (gy is tiny and cache-resident)
-    alignas(16) T bt[8];
+    // B[k = tap = 8g + j][col]: gy at the position this tap reaches (gy is tiny and cache-resident).  All 8 gathers are
+    // unconditional loads from clamped addresses (independent, in flight together); validity is applied afterwards.
+    float gval[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int tap = 8 * g + j;
       const int ih = tap / kw, iw = tap - ih * kw;
       const int hh = h - (ih - ph), ww = w - (iw - pw);
-      float v = 0.f;
-      if (tap < taps && hh >= 0 && hh < H && ww >= 0 && ww < W) v = ld<T>(gy + pc - (long)(ih - ph) * W - (iw - pw));
-      st<T>(bt + j, v);
+      const bool valid = tap < taps && hh >= 0 && hh < H && ww >= 0 && ww < W;
+      const long idx = valid ? pc - (long)(ih - ph) * W - (iw - pw) : pc;
+      const float raw = ld<T>(gy + idx);
+      gval[j] = valid ? raw : 0.f;
     }
-    const V bfr = M::load_b(bt);
-    // this lane's C/4 contiguous channels: g*(C/4) + 4*mt + r
+    // this lane's C/4 contiguous channels: g*(C/4) + 4*mt + r; the saved activations are fetched before the MFMAs
     const T* srow = save + pc * DH_C + g * (DH_C / 4);
     T* orow = gx + pc * DH_C + g * (DH_C / 4);
+    u32x4 svv[NMT / 2];
+#pragma unroll
+    for (int m2 = 0; m2 < NMT; m2 += 2) svv[m2 / 2] = *reinterpret_cast<const u32x4*>(srow + 4 * m2);
+    alignas(16) T bt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st<T>(bt + j, gval[j]);
+    const V bfr = M::load_b(bt);
 #pragma unroll
     for (int m2 = 0; m2 < NMT; m2 += 2) {
       const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(256) void dhead_dgrad_kernel(const T* __restrict__ 
       const f32x4 d1 = M::mma(M::load_b(pa + (long)(m2 + 1) * 1024), bfr, zero);
       alignas(16) T sv[8];
       alignas(16) T ov[8];
-      *reinterpret_cast<u32x4*>(sv) = *reinterpret_cast<const u32x4*>(srow + 4 * m2);
+      *reinterpret_cast<u32x4*>(sv) = svv[m2 / 2];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         st<T>(ov + r, ld<T>(sv + r) >= 0.f ? d0[r] : d0[r] * slope);
