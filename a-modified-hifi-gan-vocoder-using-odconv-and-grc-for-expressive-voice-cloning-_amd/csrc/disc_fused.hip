@@ -560,14 +560,19 @@ __global__ __launch_bounds__(256) void dtap_wgrad_kernel(const T* __restrict__ v
     __syncthreads();
     const int wend = (w0 + WT < W) ? w0 + WT : W;
     const T* vrow = vec + (((long)b * H + h) * W) * C + cg * 8;
-    // two positions per iteration: both 16-byte loads are issued before the FMAs of either
+    // two positions per iteration, software-pipelined: the loads of the NEXT pair are in flight during this pair's FMAs
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto ldpos = [&](int wq) { return wq < wend ? *reinterpret_cast<const u32x4*>(vrow + (long)wq * C) : zero4; };
+    u32x4 nx = ldpos(w0 + part), nx2 = ldpos(w0 + part + nparts);
     for (int w = w0 + part; w < wend; w += 2 * nparts) {
       const int w2 = w + nparts;
       const bool two = w2 < wend;
       alignas(16) T tmp[8];
       alignas(16) T tmp2[8];
-      *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(vrow + (long)w * C);
-      *reinterpret_cast<u32x4*>(tmp2) = two ? *reinterpret_cast<const u32x4*>(vrow + (long)w2 * C) : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(tmp) = nx;
+      *reinterpret_cast<u32x4*>(tmp2) = nx2;
+      nx = ldpos(w + 2 * nparts);
+      nx2 = ldpos(w2 + 2 * nparts);
       float v[8], v2[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { v[e] = ld<T>(tmp + e); v2[e] = ld<T>(tmp2 + e); }
