@@ -1054,12 +1054,13 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
     static int force = -2;
     if (force == -2) { const char* e = getenv("MV_DCONV_WIDE"); force = e ? atoi(e) : -1; }
     const size_t full = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(Cin * 2, 2);
-    bool use = full > 160 * 1024 || Cin > 128 || (kh == 3 && Cin >= 64 && Cout <= 128) || (kh == 1 && Cin == 64 && Cout == 32);
+    const bool big3x3 = kh == 3 && Cin == 128 && Cout >= 256;      // 256 rows per workgroup: 4 M-tiles per B fragment
+    bool use = full > 160 * 1024 || Cin > 128 || (kh == 3 && Cin >= 64 && Cout <= 128) || (kh == 1 && Cin == 64 && Cout == 32) || big3x3;
     if (force >= 0) use = force != 0;
     p.cchunk = Cin > 128 ? 128 : Cin;
     if (use && Cin % p.cchunk == 0 && (p.cchunk == 128 || p.cchunk == 64 || p.cchunk == 32)) {
       const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(p.cchunk * 2, 2);
-      const int rows = Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
+      const int rows = big3x3 ? 256 : Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
       const size_t ob = (size_t)128 * (rows * 2 + 16);
       const size_t ldsb = xb > ob ? xb : ob;
       if (ldsb <= 160 * 1024) {
@@ -1070,7 +1071,7 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
           static size_t lds_set_w = 0; \
           if (ldsb > lds_set_w) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_w = ldsb; } \
           hipLaunchKernelGGL(kern, grid, dim3(512), ldsb, st_, (const TT*)x, (const TT*)packed, (const TT*)bias, (const TT*)act_save, (TT*)y, p); } while (0)
-#define MV_WIDE_R(TT, CC_) do { if (rows == 128) MV_WIDE(TT, 2, 2, 4, CC_); else if (rows == 64) MV_WIDE(TT, 4, 2, 2, CC_); else MV_WIDE(TT, 4, 1, 2, CC_); } while (0)
+#define MV_WIDE_R(TT, CC_) do { if (rows == 256) MV_WIDE(TT, 2, 4, 4, CC_); else if (rows == 128) MV_WIDE(TT, 2, 2, 4, CC_); else if (rows == 64) MV_WIDE(TT, 4, 2, 2, CC_); else MV_WIDE(TT, 4, 1, 2, CC_); } while (0)
 #define MV_WIDE_T(TT) do { if (p.cchunk == 128) MV_WIDE_R(TT, 128); else if (p.cchunk == 64) MV_WIDE_R(TT, 64); else MV_WIDE_R(TT, 32); } while (0)
         if (dtype == MV_BF16) MV_WIDE_T(bf16); else MV_WIDE_T(f16);
 #undef MV_WIDE_T
