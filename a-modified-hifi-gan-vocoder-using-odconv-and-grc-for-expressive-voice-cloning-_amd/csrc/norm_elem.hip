@@ -42,6 +42,49 @@ __global__ __launch_bounds__(256) void odconv_attn_kernel(const T* __restrict__ 
   }
 }
 
+// long inputs: the per-channel means come from a chip-wide launch (one wave per (sample, channel) row, 16-byte loads),
+// then one small workgroup per sample forms the logits and the softmax from them
+template <typename T>
+__global__ __launch_bounds__(256) void rowmean_kernel(const T* __restrict__ x, float* __restrict__ pooled, long nrows, int Tn) {
+  constexpr int EPV = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const T* p = x + row * Tn;
+  float s = 0.f;
+  if (Tn % EPV == 0 && ((uintptr_t)x & 15) == 0) {
+    for (int t = lane * EPV; t < Tn; t += 64 * EPV) {
+      alignas(16) T tmp[EPV];
+      *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(p + t);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s += ld<T>(tmp + e);
+    }
+  } else {
+    for (int t = lane; t < Tn; t += 64) s += ld<T>(p + t);
+  }
+  s = wave_sum(s);
+  if (lane == 0) pooled[row] = s / (float)Tn;
+}
+template <typename T>
+__global__ __launch_bounds__(64) void odconv_attn_pooled_kernel(const float* __restrict__ pooled, const T* __restrict__ w,
+                                                                const T* __restrict__ bias, float* __restrict__ alpha, int C, int K) {
+  __shared__ float logit[64];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ld<T>(w + (long)k * C + c) * pooled[(long)b * C + c];
+    s = wave_sum(s);
+    if (lane == 0) logit[k] = s + (bias ? ld<T>(bias + k) : 0.f);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float m = -INFINITY, den = 0.f;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, logit[k]);
+    for (int k = 0; k < K; ++k) den += expf(logit[k] - m);
+    for (int k = 0; k < K; ++k) alpha[(long)b * K + k] = expf(logit[k] - m) / den;
+  }
+}
+
 // ---------------------------------------------------------------- generator prologue (one launch, one workgroup per sample)
 // Everything the channels-last generator needs before its first conv, fused: (1) input_proj's ODConv attention
 // alpha = softmax(Wa . mean_t mel + ba) (odconv.py:36-40), (2) mel [C][T] -> channels-last [T][C], (3) the FiLM projection
@@ -340,6 +383,15 @@ extern "C" int mv_odconv_attn_fwd(const void* x, const void* w, const void* bias
   MV_CHECK_ARG(x && w && alpha && B > 0 && C > 0 && T_ > 0 && K > 0 && K <= 64);
   const size_t lds = sizeof(float) * (C + K);
   MV_CHECK_ARG(lds <= 64 * 1024);
+  if (pooled && (long)C * T_ >= 16384) {      // long rows: spread the means over the chip (B workgroups alone leave it idle)
+    const long nrows = (long)B * C;
+    MV_DISPATCH(dtype, {
+      hipLaunchKernelGGL(rowmean_kernel<T>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const T*)x, pooled, nrows, T_);
+      hipLaunchKernelGGL(odconv_attn_pooled_kernel<T>, dim3(B), dim3(64), 0, (hipStream_t)stream, pooled, (const T*)w, (const T*)bias, alpha, C, K);
+    });
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_attn_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream,
                                         (const T*)x, (const T*)w, (const T*)bias, alpha, pooled, C, T_, K));
   MV_LAUNCH_CHECK();
