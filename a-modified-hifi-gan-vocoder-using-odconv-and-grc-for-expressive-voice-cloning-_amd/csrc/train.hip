@@ -11,7 +11,7 @@ namespace mv {
 // forward (norm_elem.hip grc_fold_kernel): comb[o'][c][j] = [c in grp(o')] Wc[o'][c_loc][j] + [j==mid] s (A B)[c][o']
 //   w_eff[o][c][j] = sum_o' Wp[o][o'] comb[o'][c][j];  b_eff[o] = sum_o' Wp[o][o'] bc[o'] + bp[o]
 template <typename P>
-__global__ __launch_bounds__(256) void grc_fold_bwd_kernel(const float* __restrict__ g_weff, const float* __restrict__ g_beff,
+__global__ __launch_bounds__(1024) void grc_fold_bwd_kernel(const float* __restrict__ g_weff, const float* __restrict__ g_beff,
                                                            const P* __restrict__ conv_w, const P* __restrict__ conv_b,
                                                            const P* __restrict__ A, const P* __restrict__ Bm,
                                                            const P* __restrict__ scal, const P* __restrict__ proj_w,
@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) void grc_fold_bwd_kernel(const float* __restri
   float* gcomb = sm;                         // [Cout][Cin][ks]
   float* L = gcomb + Cout * Cin * ks;        // [Cin][Cout]
   float* red = L + Cin * Cout;               // [32]
+  float* gwl = red + 32;                     // [Cout][Cin][ks] copy of g_weff: every later loop re-reads it many times
   const int tid = threadIdx.x, nt = blockDim.x;
   const int cin_g = Cin / groups, cout_g = Cout / groups, mid = ks / 2;
   const float s = ld<P>(scal);
+  for (int i = tid; i < Cout * Cin * ks; i += nt) gwl[i] = g_weff[i];
+  __syncthreads();
   for (int i = tid; i < Cin * Cout; i += nt) {
     const int c = i / Cout, o = i % Cout;
     float l = 0.f;
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void grc_fold_bwd_kernel(const float* __restri
   for (int i = tid; i < Cout * Cin * ks; i += nt) {
     const int j = i % ks, c = (i / ks) % Cin, op = i / (ks * Cin);
     float a = 0.f;
-    for (int o = 0; o < Cout; ++o) a += ld<P>(proj_w + o * Cout + op) * g_weff[((long)o * Cin + c) * ks + j];
+    for (int o = 0; o < Cout; ++o) a += ld<P>(proj_w + o * Cout + op) * gwl[(o * Cin + c) * ks + j];
     gcomb[i] = a;
   }
   __syncthreads();
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void grc_fold_bwd_kernel(const float* __restri
         float comb = 0.f;
         if (c / cin_g == g) comb = ld<P>(conv_w + ((long)op * cin_g + (c - g * cin_g)) * ks + j);
         if (j == mid) comb += s * L[c * Cout + op];
-        a += g_weff[((long)o * Cin + c) * ks + j] * comb;
+        a += gwl[(o * Cin + c) * ks + j] * comb;
       }
     g_proj_w[i] = a;
   }
@@ -263,11 +266,11 @@ extern "C" int mv_grc_fold_bwd(const float* g_weff, const float* g_beff, const v
                                void* stream) {
   MV_CHECK_ARG(g_weff && g_beff && conv_w && conv_b && lora_A && lora_B && lora_scaling && proj_w);
   MV_CHECK_ARG(g_conv_w && g_conv_b && g_A && g_B && g_s && g_proj_w && g_proj_b && (ks & 1) && Cin % groups == 0 && Cout % groups == 0);
-  const size_t lds = sizeof(float) * ((size_t)Cout * Cin * ks + (size_t)Cin * Cout + 32);
+  const size_t lds = sizeof(float) * (2 * (size_t)Cout * Cin * ks + (size_t)Cin * Cout + 32);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
 #define GO(P) { auto kern = grc_fold_bwd_kernel<P>; \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, (hipStream_t)stream, g_weff, g_beff, (const P*)conv_w, (const P*)conv_b, \
+    hipLaunchKernelGGL(kern, dim3(1), dim3(1024), lds, (hipStream_t)stream, g_weff, g_beff, (const P*)conv_w, (const P*)conv_b, \
       (const P*)lora_A, (const P*)lora_B, (const P*)lora_scaling, (const P*)proj_w, g_conv_w, g_conv_b, g_A, g_B, g_s, g_proj_w, \
       g_proj_b, Cin, Cout, ks, groups, rank); }
   switch (param_dtype) {
