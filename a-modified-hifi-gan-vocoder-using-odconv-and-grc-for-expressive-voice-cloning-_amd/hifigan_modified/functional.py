@@ -142,7 +142,7 @@ class _Conv1d(Function):
         stride, padding, dilation, groups, act, slope = cfg
         x = x if x.stride(2) == 1 else x.contiguous()
         ctx.cfg = cfg
-        ctx.mfma = act == N.ACT_NONE and ops.mfma_conv1d_ok(x, weight, stride, padding, dilation, groups)
+        ctx.mfma = ops.mfma_conv1d_ok(x, weight, stride, padding, dilation, groups)
         if ctx.mfma:
             Cout, Cin, ks = weight.shape
             cop, cip = ops._up32(Cout), ops._up32(Cin)
@@ -154,8 +154,11 @@ class _Conv1d(Function):
                     bp = torch.zeros(cop, device=x.device, dtype=x.dtype)
                     bp[:Cout] = _w(bias, x)
             y_cl = ops.dconv_cl(x_cl, ops.dconv_pack(weight.reshape(Cout, Cin, 1, ks), x.dtype, 0, cop, cip), bp, cop, 1, ks, dilation)
-            ctx.save_for_backward(x_cl, weight, bias, None)
-            return ops.ntc_to_nct(y_cl, Cout)
+            y = ops.ntc_to_nct(y_cl, Cout)
+            if act != N.ACT_NONE:                     # activation as its own (tiny) launch on the NCT result
+                y = ops.act(y, act, slope)
+            ctx.save_for_backward(x_cl, weight, bias, y if act != N.ACT_NONE else None)
+            return y
         y = ops.conv1d(x, _w(weight, x), _w(bias, x), None, stride, padding, dilation, groups, act, slope)
         ctx.save_for_backward(x, weight, bias, y if act != N.ACT_NONE else None)
         return y
@@ -168,6 +171,8 @@ class _Conv1d(Function):
             Cout, Cin, ks = weight.shape
             cop, cip = ops._up32(Cout), ops._up32(Cin)
             gy = gy if gy.is_contiguous() else gy.contiguous()
+            if act != N.ACT_NONE:
+                gy = ops.act_bwd(gy, y, act, slope)
             g_cl = ops.nct_to_ntc(gy, cop)
             gx = gw = gb = None
             if ctx.needs_input_grad[0]:

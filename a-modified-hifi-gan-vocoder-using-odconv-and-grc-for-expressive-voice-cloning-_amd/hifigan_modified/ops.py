@@ -326,7 +326,7 @@ def mfma_conv1d_ok(x, weight, stride, padding, dilation, groups) -> bool:
         return False
     Cout, Cin, ks = weight.shape
     return (groups == 1 and stride == 1 and ks in _MFMA_KS and padding == dilation * (ks - 1) // 2
-            and (ks - 1) * dilation <= 64 and Cin >= 16 and Cout >= 16)
+            and (ks - 1) * dilation <= 64 and Cin >= 16 and Cout >= 1)
 
 
 def dconv_pack(w4, dtype, flip, coutp=None, cinp=None):

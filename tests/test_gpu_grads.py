@@ -272,7 +272,7 @@ def test_disc_fused_mfma_vs_fp32(H, dtype, kind, arg, T, slope):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("cin,cout,ks,dil,T", [(64, 64, 3, 1, 1000), (64, 64, 7, 3, 777), (64, 64, 11, 5, 1024), (192, 64, 1, 1, 300),
-                                               (32, 128, 5, 2, 130), (64, 256, 15, 1, 515), (64, 20, 3, 3, 900), (64, 20, 3, 5, 257), (60, 64, 1, 1, 640)])
+                                               (32, 128, 5, 2, 130), (64, 256, 15, 1, 515), (64, 20, 3, 3, 900), (64, 20, 3, 5, 257), (60, 64, 1, 1, 640), (64, 1, 11, 1, 1000)])
 def test_conv1d_mfma_route_vs_fp64(H, dtype, cin, cout, ks, dil, T):
     """16-bit dense 'same' Conv1d (the GRC / fusion convs, grc_lora.py:36-41,148) on the channels-last MFMA kernels:
     forward, data gradient, weight gradient (transposed-LDS-read GEMM with W-dilation) and bias gradient against an fp64
