@@ -1246,6 +1246,47 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
   return MV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ tap matrix (im2col of a one-channel map)
+// out[pos][tap] (16 taps per position, zero beyond kh*kw) = sc[pos + off(tap)]  (flip = 0)  or  sc[pos - off(tap)]  (flip = 1),
+// off(tap) = (ih - kh/2, iw - kw/2), zero outside the image.  With it the one-channel weight gradients become plain 1x1
+// weight-gradient GEMMs on the MFMA kernel:  head  gw[tap][c] = sum_pos out[pos][tap] x[pos][c]  (flip = 1, sc = output
+// gradient; column kh*kw/2 sums to the bias gradient),  first layer  gw[o][tap] = sum_pos g1[pos][o] out[pos][tap]  (flip = 0).
+template <typename T>
+__global__ __launch_bounds__(256) void tap_matrix_kernel(const T* __restrict__ sc, T* __restrict__ out, int B, int H, int W, int kh,
+                                                         int kw, int flip) {
+  const long npos = (long)B * H * W;
+  const int ph = kh / 2, pw = kw / 2, taps = kh * kw;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npos * 2; i += (long)gridDim.x * blockDim.x) {
+    const long pos = i >> 1;
+    const int half = (int)(i & 1);
+    const int w = (int)(pos % W), h = (int)((pos / W) % H);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = 8 * half + j;
+      const int ih = tap / kw, iw = tap - ih * kw;
+      const int dh = flip ? -(ih - ph) : ih - ph, dw = flip ? -(iw - pw) : iw - pw;
+      const bool valid = tap < taps && h + dh >= 0 && h + dh < H && w + dw >= 0 && w + dw < W;
+      const float raw = ld<T>(sc + (valid ? pos + (long)dh * W + dw : pos));
+      v[j] = valid ? raw : 0.f;
+    }
+    alignas(16) T o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st<T>(o8 + j, v[j]);
+    *reinterpret_cast<u32x4*>(out + pos * 16 + half * 8) = *reinterpret_cast<u32x4*>(o8);
+  }
+}
+
+extern "C" int mv_tap_matrix(const void* sc, void* out, int B, int H, int W, int kh, int kw, int flip, int dtype, void* stream) {
+  MV_CHECK_ARG(sc && out && B > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && kh * kw <= 16 && ((uintptr_t)out & 15) == 0);
+  const long n = (long)B * H * W * 2;
+  const unsigned grid = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(tap_matrix_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)sc, (T*)out, B, H, W,
+                                        kh, kw, flip));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ ODConvTranspose1d bank gradients
 // gW[k][c][o][j] = sum_b alpha[b,k] sum_t x[b,t,c] g[b, t*s + j - p, o]   and   d alpha[b,k] = <per-sample gradient, W[k]>
 // (odconv.py:172-205, ks = 2*stride).  With the time-padded gradient gp [B][Tin+1][s*Cout] (row q, channel r*Cout+o holds

@@ -160,10 +160,20 @@ class _DiscStack(Function):
         # ---- head
         C4 = ws[4].shape[1]
         if need_w:
-            gwt, gb5 = f32(kh * kw, C4), f32(1)
-            N.call("mv_dhead_wgrad", _P(gy), _P(acts[3]), _P(gwt), _P(gb5), B, H, W, C4, kh, kw, ops._dt(gy), st())
-            gw5 = f32(C4, kh * kw)                       # [taps][C] -> [C][taps] with our own transpose kernel
-            N.call("mv_ntc_to_nct", _P(gwt), _P(gw5), 1, C4, kh * kw, N.MV_F32, st())
+            taps = kh * kw
+            if taps <= 16 and C4 % 8 == 0:
+                # gw[tap][c] = sum_pos G[pos][tap] x[pos][c] with G = the flipped tap matrix of gy: a 1x1 weight-gradient GEMM
+                # on the MFMA kernel; the centre column of G sums to the bias gradient
+                tm = torch.empty(B, H, W, 16, device=dev, dtype=dt)
+                N.call("mv_tap_matrix", _P(gy), _P(tm), B, H, W, kh, kw, 1, ops._dt(gy), st())
+                gw16, gb16 = ops.dconv_wgrad_cl(acts[3], tm, 1, 1, want_bias=True)
+                gwt = gw16.view(16, C4)[:taps]
+                gb5 = gb16[taps // 2:taps // 2 + 1]
+            else:
+                gwt, gb5 = f32(taps, C4), f32(1)
+                N.call("mv_dhead_wgrad", _P(gy), _P(acts[3]), _P(gwt), _P(gb5), B, H, W, C4, kh, kw, ops._dt(gy), st())
+            gw5 = f32(C4, taps)                          # [taps][C] -> [C][taps] with our own transpose kernel
+            N.call("mv_ntc_to_nct", _P(gwt), _P(gw5), 1, C4, taps, N.MV_F32, st())
             grads[8], grads[9] = to(gw5, params[8]), to(gb5, params[9])
         g = torch.empty(B, H, W, C4, device=dev, dtype=dt)
         if C4 == 256 and kh * kw <= 16:
@@ -190,8 +200,17 @@ class _DiscStack(Function):
         # ---- first layer
         C1 = ws[0].shape[0]
         if need_w:
-            gw1, gb1 = f32(C1, kh * kw), f32(C1)
-            N.call("mv_dfirst_wgrad_cl", _P(g), _P(x0), _P(gw1), _P(gb1), B, H, W, C1, kh, kw, ops._dt(g), st())
+            taps = kh * kw
+            if taps <= 16 and C1 % 8 == 0:
+                # gw[o][tap] = sum_pos g1[pos][o] X[pos][tap] with X = the tap matrix of x0 (1x1 weight-gradient GEMM on MFMA)
+                tm = torch.empty(B, H, W, 16, device=dev, dtype=dt)
+                N.call("mv_tap_matrix", _P(x0), _P(tm), B, H, W, kh, kw, 0, ops._dt(g), st())
+                gw16, gb1 = ops.dconv_wgrad_cl(tm, g, 1, 1, want_bias=True)
+                gw1 = f32(C1, taps)
+                ops.copy_rows(gw16.view(1, C1, 16), gw1.view(1, C1, taps))
+            else:
+                gw1, gb1 = f32(C1, taps), f32(C1)
+                N.call("mv_dfirst_wgrad_cl", _P(g), _P(x0), _P(gw1), _P(gb1), B, H, W, C1, kh, kw, ops._dt(g), st())
             grads[0], grads[1] = to(gw1, params[0]), to(gb1, params[1])
         gx0 = None
         if need[0]:

@@ -337,6 +337,10 @@ int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, float* workspac
                        int dtype, void* stream);
 int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int B, int H, int W, int C1, int kh, int kw,
                        int dtype, void* stream);
+/* out [B][H][W][16] = the 16-tap "im2col" of a one-channel map sc [B][H][W]: out[pos][tap] = sc[pos + off(tap)] (flip 0) or
+ * sc[pos - off(tap)] (flip 1), zero outside the image and for tap >= kh*kw.  Turns the one-channel weight gradients of the
+ * first layer and the head (discriminators.py:57,65 / :98,106) into 1x1 weight-gradient GEMMs for mv_dconv_wgrad_cl. */
+int mv_tap_matrix(const void* sc, void* out, int B, int H, int W, int kh, int kw, int flip, int dtype, void* stream);
 /* out[c] = sum over rows of x[row][c] (bias gradient of a channels-last tensor); C divides 256. */
 int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream);
 
