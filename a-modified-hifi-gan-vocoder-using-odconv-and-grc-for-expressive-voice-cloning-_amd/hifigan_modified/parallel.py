@@ -32,6 +32,8 @@ def broadcast_parameters(module, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+        from . import ops
+        ops.bump_param_epoch()          # .data writes do not bump _version: drop every cached cast / packed weight
 
 
 def bucket_ranges(numel, bucket_elems):
