@@ -174,6 +174,35 @@ def main():
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
                 "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic"}
 
+    # ---------------------------------------------------------------- parity-grade mode (fp32 storage, bf16x3 MFMA operands)
+    # The headline runs the BASELINE-named bf16 configuration, whose waveform parity is bounded by 16-bit activation
+    # storage.  The same generator with fp32 storage meets north_star's 1e-3 tolerance; its
+    # throughput and parity are reported beside the headline (rank 0, N=1 only; same workload, same HIP-graph replay).
+    parity_grade = None
+    if rank == 0 and world == 1 and dtype != torch.float32 and not args.eager:
+        from hifigan_modified.graphs import GraphedVocoder
+        from oracle import vocoder_oracle as O
+        g32 = H.ModifiedHiFiGANGenerator()
+        g32.load_state_dict(sd_cpu)
+        g32 = g32.to(dev).train(False)
+        m32, s32, e32 = mel.float(), spk.float(), emo.float()
+        with torch.no_grad():
+            w32 = g32(m32[:2], s32[:2], e32[:2]).cpu()
+            ref = O.generator_forward(m32[:2].cpu(), sd_cpu, "", s32[:2].cpu(), e32[:2].cpu())
+        gv32 = GraphedVocoder(g32, m32, s32, e32)
+        for _ in range(20):
+            gv32.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n32 = 200
+        for _ in range(n32):
+            gv32.replay()
+        torch.cuda.synchronize()
+        el32 = time.perf_counter() - t1
+        parity_grade = {"dtype": "fp32", "value": round(B * Tm * n32 / el32, 1), "unit": "mel-frames/s",
+                        "ms_per_step": round(el32 / n32 * 1e3, 4), "parity_rel_l2_vs_oracle": O.rel_l2(w32, ref)}
+        del gv32, g32
+
     # ---------------------------------------------------------------- training metric (BASELINE configs[2]/[3])
     # full two-optimizer step (complete_vocoder.py:199-233): G forward -> D step -> G step, + mel/STFT loss, + AdamW;
     # data parallel: 32 clips per GPU, one all-reduce of the flat gradient buffer per optimizer step (RCCL)
@@ -251,6 +280,7 @@ def main():
             "samples_per_s": round(frames * 256 / elapsed, 1),
             "parity_rel_l2_vs_oracle": parity, "launch": "eager" if args.eager else "hipgraph",
             "roofline": roof,
+            "parity_grade": parity_grade,
             "train": train,
         }
         if not args.no_cpu_baseline and world == 1:
