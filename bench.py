@@ -29,24 +29,43 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(sd, n_threads, budget_s=20.0):
-    """Oracle (reference formulation: K shared-weight convs + alpha-weighted sum) on the host cores."""
+def cpu_baseline(sd, n_threads, budget_s=24.0):
+    """Oracle (reference formulation: K shared-weight convs + alpha-weighted sum) on the host cores, fp32.
+    torch's CPU convolutions do not scale to every core of a 2-socket box, so a few thread counts share the time budget and
+    the best one is reported as `value` (with its `cores`); the whole sweep, the single-thread figure SURVEY 8(d) asks for
+    and the CPU model are kept beside it."""
     from oracle import vocoder_oracle as O
-    torch.set_num_threads(n_threads)
     torch.manual_seed(1)
-    B, Tm = 8, 32
-    mel, spk, emo = torch.randn(B, 80, Tm), torch.randn(B, 192), torch.randn(B, 384)
-    with torch.no_grad():
-        O.generator_forward(mel, sd, "", spk, emo)  # warm-up
-        t0, n = time.perf_counter(), 0
-        while True:
-            O.generator_forward(mel, sd, "", spk, emo)
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget_s or n >= 50:
-                break
-    return {"value": round(B * Tm * n / el, 1), "unit": "mel-frames/s", "cores": n_threads, "kind": "port",
-            "sample": f"{n} forwards of B={B} x {Tm} frames, fp32, oracle K-loop form, {el:.1f} s"}
+    Tm = 32
+    mel8, spk8, emo8 = torch.randn(8, 80, Tm), torch.randn(8, 192), torch.randn(8, 384)
+
+    def run(threads, B, budget):
+        torch.set_num_threads(threads)
+        mel, spk, emo = mel8[:B], spk8[:B], emo8[:B]
+        with torch.no_grad():
+            O.generator_forward(mel, sd, "", spk, emo)  # warm-up
+            t0, n = time.perf_counter(), 0
+            while True:
+                O.generator_forward(mel, sd, "", spk, emo)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget or n >= 50:
+                    break
+        return {"cores": threads, "batch": B, "value": round(B * Tm * n / el, 1), "forwards": n, "seconds": round(el, 1)}
+
+    cands = sorted({1, min(16, n_threads), min(32, n_threads), n_threads})
+    sweep = [run(t, 1 if t == 1 else 8, budget_s / len(cands)) for t in cands]
+    best = max(sweep, key=lambda r: r["value"])
+    out = {"value": best["value"], "unit": "mel-frames/s", "cores": best["cores"], "kind": "port",
+           "sample": "%d forwards of B=%d x %d frames, fp32, oracle K-loop form, %.1f s (best of the thread sweep)"
+                     % (best["forwards"], best["batch"], Tm, best["seconds"]),
+           "value_1thread": sweep[0]["value"], "sweep": sweep}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            out["cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
+    except OSError:
+        out["cpu_model"] = "unknown"
+    return out
 
 
 def main():
@@ -174,6 +193,33 @@ def main():
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
                 "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic"}
 
+    # per-kernel HBM figures of the HBM-bound fused ODConvTranspose1d launches ((Cin/f + Cout) * 2 B per output sample)
+    od_roof = None
+    if rank == 0 and fz is not None:
+        od_roof = []
+        with torch.no_grad():
+            for li in (len(fz.ups) - 2, len(fz.ups) - 1):
+                u = fz.ups[li]
+                xin = ops.nct_to_ntc(st["up%d" % (li - 1)] if li > 0 else st["film"])
+                pooled = xin.float().sum(dim=1).contiguous()
+                from hifigan_modified import functional as _Fn
+                run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1)
+                y = run()
+                for _ in range(5):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms_u = e0.elapsed_time(e1) / 50
+                byts = (xin.numel() + y.numel()) * elt
+                od_roof.append({"kernel": "mv::odconv_cl_kernel (upsample_layers.%d: %d->%d ch, x%d)" % (li, u.mod.in_channels, u.mod.out_channels, u.mod.stride),
+                                "bound": "hbm", "achieved": round(byts / (ms_u * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(byts / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": byts,
+                                "ms_per_launch": round(ms_u, 4)})
+
     # ---------------------------------------------------------------- parity-grade mode (fp32 storage, bf16x3 MFMA operands)
     # The headline runs the BASELINE-named bf16 configuration, whose waveform parity is bounded by 16-bit activation
     # storage.  The same generator with fp32 storage meets north_star's 1e-3 tolerance; its
@@ -280,6 +326,7 @@ def main():
             "samples_per_s": round(frames * 256 / elapsed, 1),
             "parity_rel_l2_vs_oracle": parity, "launch": "eager" if args.eager else "hipgraph",
             "roofline": roof,
+            "roofline_odconv": od_roof,
             "parity_grade": parity_grade,
             "train": train,
         }
