@@ -369,3 +369,51 @@ def test_plain_hifigan_v3_vs_cpu_restatement(H, dtype, tol, Tm):
     y = g.cuda().to(dtype).train(False)(mel.cuda().to(dtype))
     assert y.shape == (1, 1, Tm * 256) and y.dtype == dtype
     assert O.rel_l2(y.float().cpu(), ref) < tol
+
+
+def test_full_c2_batch_properties(H):
+    """BASELINE configs[1] at its full size (B=32 clips x 32 mel frames -> 8192 samples, default generator) through
+    size-independent properties, since the CPU oracle takes seconds per clip:
+    (1) per-sample independence - every op of the path is per-sample, so clip i of the batch equals clip i vocoded alone
+        (this also exercises the batch-dependent kernel selection: K-loop vs aggregate ODConv, samples per workgroup);
+    (2) three of the 32 clips against the oracle (fp32 storage, north_star's 1e-3 waveform tolerance, measured ~2e-5);
+    (3) the waveform is finite and inside tanh's range."""
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator()
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.cuda().train(False)
+    torch.manual_seed(1)
+    mel, spk, emo = torch.randn(32, 80, 32), torch.randn(32, 192), torch.randn(32, 384)
+    with torch.no_grad():
+        wave = gen(mel.cuda(), spk.cuda(), emo.cuda())
+        assert wave.shape == (32, 1, 8192)
+        assert bool(torch.isfinite(wave).all()) and float(wave.abs().max()) <= 1.0
+        for i in (0, 13, 31):
+            solo = gen(mel[i:i + 1].cuda(), spk[i:i + 1].cuda(), emo[i:i + 1].cuda())
+            assert O.rel_l2(wave[i:i + 1].cpu(), solo.cpu()) < 1e-4, i
+            ref = O.generator_forward(mel[i:i + 1], sd, "", spk[i:i + 1], emo[i:i + 1])
+            assert O.rel_l2(wave[i:i + 1].cpu(), ref) < 1e-3, i
+
+
+@pytest.mark.parametrize("kind,arg", [("2d", 2), ("2d", 11), ("1d", 1)])
+def test_full_size_discriminator_is_affine_when_slope_is_one(H, kind, arg):
+    """Discriminator stacks at the training size (B=32 x 8192 samples, bf16 MFMA path): with LeakyReLU slope 1 the stack is
+    affine, so f(a x + (1-a) y) = a f(x) + (1-a) f(y) up to rounding - a size-independent check of the channels-last MFMA
+    kernels (all tile paths, image edges, the tap-row head) where an fp64 reference of the whole batch would take minutes."""
+    from hifigan_modified import disc_fused, functional as Fn
+    torch.manual_seed(0)
+    m = (H.Discriminator2D(arg) if kind == "2d" else H.Discriminator1D(arg)).cuda()
+    torch.manual_seed(1)
+    x = torch.randn(32, 1, 8192, device="cuda").clamp(-1, 1)
+    y = torch.randn(32, 1, 8192, device="cuda").clamp(-1, 1)
+    a = 0.25
+
+    def f(t):
+        t = t.to(torch.bfloat16)
+        t0 = (Fn._MpdFold.apply(t, arg) if 8192 % arg else t.view(32, 1, arg, 8192 // arg)) if kind == "2d" else t
+        with torch.no_grad():
+            return disc_fused.disc_stack(t0, m, slope=1.0).float()
+
+    lhs = f(a * x + (1 - a) * y)
+    rhs = a * f(x) + (1 - a) * f(y)
+    assert O.rel_l2(lhs.cpu(), rhs.cpu()) < 2e-2
