@@ -309,7 +309,7 @@ def main():
             ms = e0.elapsed_time(e1) / 10
             flops = 2.0 * Bd * Hd * Wd * 256 * 128 * 9
             ach = flops / (ms * 1e-3) / 1e12
-            train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_wide_kernel<bf16,2,4,4,128> (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM, 8 waves x 256 rows)",
+            train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_wide_kernel<bf16,2,4,8,64> (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM, 8 waves: 256 rows x 256 positions)",
                                  "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                  "traffic": None, "flops_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
