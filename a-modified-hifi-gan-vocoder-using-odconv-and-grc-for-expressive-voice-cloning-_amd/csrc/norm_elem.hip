@@ -131,14 +131,39 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
     a = wave_sum(a);
     if (lane == 0) mean[c] = a * inv;
   }
-  // FiLM projection: wave per output row
-  if (film_proj)
-    for (int j = wid; j < F2; j += 4) {
-      float a = 0.f;
-      for (int i = lane; i < cond_dim; i += 64) a += ld<T>(film_w + (long)j * cond_dim + i) * cond[i];
-      a = wave_sum(a);
-      if (lane == 0) st<T>(film_proj + (long)b * F2 + j, a + (film_b ? ld<T>(film_b + j) : 0.f));
+  // FiLM projection: a wave owns 4 output rows at a time (their loads are independent and in flight together); 16-bit
+  // weights are read 16 bytes per lane
+  if (film_proj) {
+    constexpr int EPV = 16 / sizeof(T);
+    const bool vec = sizeof(T) == 2 && cond_dim % EPV == 0 && ((uintptr_t)film_w & 15) == 0;
+    for (int j0 = wid * 4; j0 < F2; j0 += 16) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        for (int pc = lane; pc < cond_dim / EPV; pc += 64) {
+          uint4 wv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wv[r] = *reinterpret_cast<const uint4*>(film_w + (long)(j0 + r < F2 ? j0 + r : F2 - 1) * cond_dim + pc * EPV);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            alignas(16) T tmp[EPV];
+            *reinterpret_cast<uint4*>(tmp) = wv[r];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) a[r] += ld<T>(tmp + e) * cond[pc * EPV + e];
+          }
+        }
+      } else {
+        for (int i = lane; i < cond_dim; i += 64)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] += ld<T>(film_w + (long)(j0 + r < F2 ? j0 + r : F2 - 1) * cond_dim + i) * cond[i];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = wave_sum(a[r]);
+        if (lane == 0 && j0 + r < F2) st<T>(film_proj + (long)b * F2 + j0 + r, v + (film_b ? ld<T>(film_b + j0 + r) : 0.f));
+      }
     }
+  }
   __syncthreads();
   for (int k = wid; k < K; k += 4) {
     float a = 0.f;

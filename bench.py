@@ -68,6 +68,40 @@ def cpu_baseline(sd, n_threads, budget_s=24.0):
     return out
 
 
+def graph_time_ms(run, inner=20, outer=5):
+    """Average duration (ms) of one `run()` with the launches captured in a HIP graph (inner copies per replay), timed with
+    HIP events on the launch stream: eager Python issue can be slower than these short kernels, which would time the host."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner):
+            run()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(outer):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    t_graph = e0.elapsed_time(e1) / (inner * outer)
+    # eager issue keeps the queue full when the host is faster than the kernels (then the events see back-to-back launches
+    # without the graph's per-node dependency gaps); whichever way the host was not the bottleneck is the smaller figure
+    e0.record()
+    for _ in range(inner * outer):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    t_eager = e0.elapsed_time(e1) / (inner * outer)
+    return min(t_graph, t_eager)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,16 +205,7 @@ def main():
             st = gen(mel, spk, emo, return_stages=True)
             x_cl = ops.nct_to_ntc(st["up%d" % (len(gen.upsample_layers) - 1)])
             run = (lambda: fz.mrfs[0].forward_cl(x_cl)) if fz is not None else (lambda: gen.mrf_blocks[0](st["up3"]))
-            for _ in range(5):
-                run()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 50
-            e0.record()
-            for _ in range(reps):
-                run()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
+            ms = graph_time_ms(run)
         elt = torch.tensor([], dtype=dtype).element_size()
         alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block, once (256 B / sample in bf16)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
@@ -205,15 +230,7 @@ def main():
                 from hifigan_modified import functional as _Fn
                 run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1)
                 y = run()
-                for _ in range(5):
-                    run()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    run()
-                e1.record()
-                torch.cuda.synchronize()
-                ms_u = e0.elapsed_time(e1) / 50
+                ms_u = graph_time_ms(run)
                 byts = (xin.numel() + y.numel()) * elt
                 od_roof.append({"kernel": "mv::odconv_cl_kernel (upsample_layers.%d: %d->%d ch, x%d)" % (li, u.mod.in_channels, u.mod.out_channels, u.mod.stride),
                                 "bound": "hbm", "achieved": round(byts / (ms_u * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
