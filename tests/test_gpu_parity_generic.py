@@ -417,3 +417,21 @@ def test_full_size_discriminator_is_affine_when_slope_is_one(H, kind, arg):
     lhs = f(a * x + (1 - a) * y)
     rhs = a * f(x) + (1 - a) * f(y)
     assert O.rel_l2(lhs.cpu(), rhs.cpu()) < 2e-2
+
+
+@pytest.mark.parametrize("Tm", [344, 1000])
+def test_long_utterance_takes_the_unfused_prologue(H, Tm):
+    """A long utterance (4 s = 344 frames; 11.6 s = 1000 frames) does not fit the one-workgroup-per-sample prologue kernel
+    (mv_gen_prologue returns MV_ERR_UNSUPPORTED) and the channels-last pipeline falls back to its separate HIP launches;
+    ragged tile edges of every fused kernel are exercised at lengths that are not multiples of the tile sizes."""
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator()
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.cuda().train(False)
+    torch.manual_seed(1)
+    mel, spk, emo = torch.randn(1, 80, Tm), torch.randn(1, 192), torch.randn(1, 384)
+    with torch.no_grad():
+        wave = gen(mel.cuda(), spk.cuda(), emo.cuda())
+    assert wave.shape == (1, 1, Tm * 256)
+    ref = O.generator_forward(mel, sd, "", spk, emo)
+    assert O.rel_l2(wave.cpu(), ref) < 1e-3
