@@ -113,11 +113,13 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
       dst[mw] = M::load_b(wlane + ((long)mt * p.ksteps + kstep) * 1024);
     }
   };
+  // unconditional fetches (clamped to the last k-step): a branch around the loads would force vmcnt(0) at every k-step
+  const int klast = p.ksteps - 1;
   wfetch(0, a0);
-  if (p.ksteps > 1) wfetch(1, a1);
+  wfetch(klast < 1 ? klast : 1, a1);
   int tap = 0, c32 = 0;
   for (int kstep = 0; kstep < p.ksteps; ++kstep) {
-    if (kstep + 2 < p.ksteps) wfetch(kstep + 2, a2);
+    wfetch(kstep + 2 < p.ksteps ? kstep + 2 : klast, a2);
     const int ih = tap / p.kw, iw = tap % p.kw;
     const char* bbase = lds + ((long)ih * prow + iw * p.dil + col) * RS + (c32 * 32 + 8 * g) * ES;
 #pragma unroll
@@ -253,13 +255,16 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
   // k-steps in execution order: chunk-major, then tap, then the 4 channel blocks of the chunk
   constexpr int cc32 = CCH / 32;
   int fck = 0, ftap = 0, fj = 0, fetched = 0;
+  // The fetch is UNCONDITIONAL (past the last k-step it re-reads the last fragment): a branch around the loads makes the
+  // compiler wait for vmcnt(0) at every k-step, i.e. for the fragments it has just requested - the prefetch distance is lost.
   auto fetch_next = [&](V (&dst)[MW]) {
     wfetch(ftap * p.cin32 + fck * cc32 + fj, dst);
-    ++fetched;
-    if (++fj == cc32) { fj = 0; if (++ftap == taps) { ftap = 0; ++fck; } }
+    if (++fetched < p.ksteps) {                       // scalar cursor update only; the last k-step id stays put
+      if (++fj == cc32) { fj = 0; if (++ftap == taps) { ftap = 0; ++fck; } }
+    }
   };
   fetch_next(a0);
-  if (p.ksteps > 1) fetch_next(a1);
+  fetch_next(a1);
   for (int ck = 0; ck < nchunks; ++ck) {
     if (ck) __syncthreads();
     stage(ck);
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
       const char* brow = lds + ((long)ih * prow + iw * p.dil + ps * NB * 16 + col) * RS + 8 * g * ES;
 #pragma unroll
       for (int j = 0; j < cc32; ++j) {
-        if (fetched < p.ksteps) fetch_next(a2);
+        fetch_next(a2);
         V bf[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) bf[n] = M::load_b(brow + j * 32 * ES + (long)(n * 16) * RS);
