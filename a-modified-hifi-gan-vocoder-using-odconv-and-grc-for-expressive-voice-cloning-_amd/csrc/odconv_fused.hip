@@ -16,6 +16,7 @@
 // The x tiles of the S samples live in LDS (row stride padded by 16 B); bank weights stream from L2 in packed
 // A-fragment order (one coalesced 1 KB load per bank per fragment) and are reused for the S samples.
 #include "mfma.h"
+#include <cstdlib>
 #include <cstdio>
 
 namespace mv {
@@ -212,7 +213,9 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   while (c8 >= cpc) { c8 -= cpc; ++tap; }
   for (int kstep = 0; kstep < p.ksteps; ++kstep) {
     typename WL::R wn[MW][KB];
-    if (PF && kstep + 1 < p.ksteps) wload(kstep + 1, wn);        // next fragments travel L2 -> registers under this step's math
+    // next fragments travel L2 -> registers under this step's math; the load is unconditional (clamped to the last k-step):
+    // a branch around it makes the compiler wait for vmcnt(0), i.e. for the fragments it has just requested
+    if (PF) wload(kstep + 1 < p.ksteps ? kstep + 1 : p.ksteps - 1, wn);
     // per-sample kernels for this k-step: sum_kb alpha[s,kb] * W[kb]  (fp32, then one rounding to the operand type)
     V afr[S][MW];
 #pragma unroll
@@ -243,15 +246,13 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
         for (int mw = 0; mw < MW; ++mw) acc[s][mw][n] = M::mma(afr[s][mw], bfr[n], acc[s][mw][n]);
     }
     if (PF) {
-      if (kstep + 1 < p.ksteps) {
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw)
+      for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb)
-            if (kb < p.K) wr[mw][kb] = wn[mw][kb];
-      }
-    } else if (kstep + 1 < p.ksteps) {
-      wload(kstep + 1, wr);
+        for (int kb = 0; kb < KB; ++kb)
+          if (kb < p.K) wr[mw][kb] = wn[mw][kb];
+    } else {
+      wload(kstep + 1 < p.ksteps ? kstep + 1 : p.ksteps - 1, wr);
     }
     c8 += 4;
     while (c8 >= cpc) { c8 -= cpc; ++tap; }
@@ -709,8 +710,12 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
   const long wbytes = (long)K * p.M * p.ksteps * 32 * (dtype == MV_F32 ? 4 : 2);
   int rc = MV_ERR_DTYPE;
   hipStream_t st_ = (hipStream_t)stream;
+  // with the unconditional (clamped) prefetch the prefetching instantiation wins for the short-K upsamplers as well
+  // (ups3 48 -> 44 us); MV_OD_PF=0 selects the non-prefetching one for comparison
+  static int force_pf = -1;
+  if (force_pf < 0) { const char* e = getenv("MV_OD_PF"); force_pf = e ? atoi(e) : 1; }
 #define OD_GO(S_, MW_, NB_) do { \
-    if (K <= 4 && p.ksteps <= 8) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
+    if (K <= 4 && p.ksteps <= 8 && !force_pf) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
     else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
     else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); } while (0)
   MV_DISPATCH(dtype, {
