@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       const char* wbase = wlane + ((long)mt * p.ksteps + kstep) * 512 * ES;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
-        if (kb < p.K) dst[mw][kb] = WL::load(wbase + kb * bank_stride);
+        dst[mw][kb] = WL::load(wbase + (kb < p.K ? kb : 0) * bank_stride);   // unconditional: alpha of a missing bank is 0
     }
   };
   typename WL::R wr[MW][KB];
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-          if (kb < p.K) WL::fma8(wr[mw][kb], al[s][kb], f);
+          WL::fma8(wr[mw][kb], al[s][kb], f);
         afr[s][mw] = make_a<T>(f);
       }
     // B operands: x[q + shift(tap)][8*c8 ..], loaded just in time
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
-          if (kb < p.K) wr[mw][kb] = wn[mw][kb];
+          wr[mw][kb] = wn[mw][kb];
     } else {
       wload(kstep + 1 < p.ksteps ? kstep + 1 : p.ksteps - 1, wr);
     }
@@ -433,15 +433,18 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   V ring[PD];
   const char* wcur = wlane;                          // address of fragment `fetched`
   int fetched = 0, fks = 0;
+  // the load itself is UNCONDITIONAL (past the last fragment the cursor stops and the last one is re-read): a branch around a
+  // prefetch makes the compiler wait for vmcnt(0) before every use
   auto wnext = [&]() {
     const V r = M::load_b(wcur);
-    ++fetched;
-    if (++fks == p.ksteps) { fks = 0; wcur += bank_stride - (long)(p.ksteps - 1) * 512 * ES; }
-    else wcur += 512 * ES;
+    if (++fetched < total) {
+      if (++fks == p.ksteps) { fks = 0; wcur += bank_stride - (long)(p.ksteps - 1) * 512 * ES; }
+      else wcur += 512 * ES;
+    }
     return r;
   };
 #pragma unroll
-  for (int i = 0; i < PD; ++i) ring[i] = (fetched < total) ? wnext() : ring[0];
+  for (int i = 0; i < PD; ++i) ring[i] = wnext();
   // per-lane LDS byte offsets of the B operand for each of the (at most two) taps and column tiles, clamped to the zero row
   const int cpc = p.Cin / 8;                         // multiple of 4 here: a k-step never straddles two taps
   const int sample_stride = p.nrows * RS;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
         for (int j = 0; j < PD; ++j) {
           const int ks = ks0 + j;
           const V a0 = ring[j];
-          if (fetched < total) ring[j] = wnext();
+          ring[j] = wnext();
           const int tap = (4 * ks >= cpc) ? 1 : 0;                  // wave-uniform (ntaps <= 2)
           const unsigned koff = (unsigned)((4 * ks - tap * cpc) * 8 * ES);
           // all B fragments first (independent LDS reads in flight together), then the MFMAs
