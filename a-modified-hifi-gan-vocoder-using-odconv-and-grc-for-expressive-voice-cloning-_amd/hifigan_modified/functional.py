@@ -303,14 +303,22 @@ def film(x, cond, proj_w, proj_b, feature_dim):
     return _Film.apply(x, cond, proj_w, proj_b, feature_dim)
 
 
+def _wants_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
 def film2(x, spk, emo, scale_w, scale_b, shift_w, shift_b):
-    """generator.py:187-199: (W_s e + b_s) * x + (W_h e + b_h), e = spk + emo.  Forward only."""
+    """generator.py:187-199: (W_s e + b_s) * x + (W_h e + b_h), e = spk + emo.
+    Training: the two projections are one FiLM projection [W_s; W_h] (parameter-sized concatenation) through `_Film`, so
+    x, the embeddings and all four parameters receive gradients from the HIP backward kernels."""
+    if _wants_grad(x, spk, emo, scale_w, scale_b, shift_w, shift_b):
+        e = spk + emo                                             # [B, D] host-side glue
+        return film(x, e, torch.cat([scale_w, shift_w], 0), torch.cat([scale_b, shift_b], 0), scale_w.shape[0])
     with torch.no_grad():
         e = ops.act(ops.cast(spk, x.dtype), N.ACT_NONE, res=ops.cast(emo, x.dtype))
         scale = ops.linear(e, _w(scale_w, x), _w(scale_b, x))
         shift = ops.linear(e, _w(shift_w, x), _w(shift_b, x))
-        y = ops.scale_shift(x, scale, shift)
-    return _track("film2", y, x, spk, emo, scale_w, scale_b, shift_w, shift_b)
+        return ops.scale_shift(x, scale, shift)
 
 
 # ----------------------------------------------------------------------------------------------- GRC + LoRA / MRF (generic shapes)
@@ -408,8 +416,35 @@ def mrf_block(x, blk, force_generic=False, mask=None):
     return group_norm(f, blk.norm.weight, blk.norm.bias, blk.norm_groups, blk.norm.eps, res=x, mask=mask, mask_scale=scale)
 
 
+def _grouped_residual_dense_weights(blk):
+    """Parameter algebra of generator.py:141-165 (parameter-sized, differentiable torch glue): the grouped conv and the
+    shared-across-groups LoRA map alpha * (B A) become ONE dense block-diagonal kernel [C, C, k]; the 1x1 channel mixer
+    and the residual `+ x` become ONE 1x1 kernel [C, 2C] over cat(u, x)."""
+    G, C, k = blk.groups, blk.channels, blk.kernel_size
+    cg = C // G
+    wg = blk.grouped_conv.weight                                   # [C, C/G, k]
+    M = blk.lora_alpha * (blk.lora_B @ blk.lora_A)                 # [C/G, C/G]
+    dense = wg.new_zeros(C, C, k)
+    for gi in range(G):
+        blkw = wg[gi * cg:(gi + 1) * cg].clone()
+        blkw[:, :, k // 2] = blkw[:, :, k // 2] + M
+        dense[gi * cg:(gi + 1) * cg, gi * cg:(gi + 1) * cg] = blkw
+    eye = torch.eye(C, device=wg.device, dtype=wg.dtype).unsqueeze(-1)
+    mix = torch.cat([blk.channel_mixer.weight, eye], dim=1)        # [C, 2C, 1]
+    return dense, mix
+
+
 def grouped_residual_conv1d(x, blk):
-    """generator.py:141-172: LeakyReLU(GN_G(Conv1x1(conv_g(x) + alpha*LoRA_g(x)) + x)).  Forward only."""
+    """generator.py:141-172: LeakyReLU(GN_G(Conv1x1(conv_g(x) + alpha*LoRA_g(x)) + x)).
+    Training runs the folded dense form through the differentiable conv / concat / GroupNorm functions (MFMA kernels for
+    16-bit storage); inference keeps the grouped kernels."""
+    if _wants_grad(x, *blk.parameters()):
+        x = x if x.is_contiguous() else x.contiguous()
+        k, d = blk.kernel_size, blk.dilation
+        dense, mix = _grouped_residual_dense_weights(blk)
+        u = conv1d(x, dense, blk.grouped_conv.bias, padding=(k - 1) * d // 2, dilation=d)
+        m = conv1d(_Cat.apply(u, x), mix, blk.channel_mixer.bias)
+        return group_norm(m, blk.norm.weight, blk.norm.bias, blk.groups, blk.norm.eps, act="lrelu", slope=0.1)
     with torch.no_grad():
         x = x if x.is_contiguous() else x.contiguous()
         G, C = blk.groups, blk.channels
@@ -424,8 +459,7 @@ def grouped_residual_conv1d(x, blk):
         u = ops.conv1d(x, wl, None, None, 1, 0, 1, G, res=h)
         m = ops.conv1d(u, _w(blk.channel_mixer.weight, x), _w(blk.channel_mixer.bias, x), res=x)
         mean, rstd = ops.groupnorm_stats(m, G, blk.norm.eps)
-        y = ops.groupnorm_apply(m, mean, rstd, _w(blk.norm.weight, x), _w(blk.norm.bias, x), G, act=N.ACT_LRELU, slope=0.1)
-    return _track("grouped_residual_conv1d", y, x, *blk.parameters())
+        return ops.groupnorm_apply(m, mean, rstd, _w(blk.norm.weight, x), _w(blk.norm.bias, x), G, act=N.ACT_LRELU, slope=0.1)
 
 
 # ----------------------------------------------------------------------------------------------- discriminators

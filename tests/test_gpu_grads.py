@@ -338,3 +338,17 @@ def test_odconv_transpose_mfma_data_gradient_vs_fp64(H, dtype, cin, cout, ks, st
     assert O.rel_l2(md.bias.grad.cpu(), bk.grad) < eps
     assert O.rel_l2(md.kernel_attention[1].weight.grad.cpu(), Wa.grad) < 3 * eps
     assert O.rel_l2(md.kernel_attention[1].bias.grad.cpu(), ba.grad) < 3 * eps
+
+
+def test_second_design_blocks_grads(H):
+    """GroupedResidualConv1D (generator.py:112-172) and FeatureWiseLinearModulation (generator.py:177-199) against the
+    reference's gradient goldens: input gradients (for film2 also both embeddings) and every parameter gradient, through the
+    folded dense-kernel form on the HIP backward kernels."""
+    g = load_golden("grouped_residual_64_k3_d3")
+    m = load_sd(H.GroupedResidualConv1D(64, 3, 3), g)
+    x = gin(g, "x.x")
+    check_all(g, m, m(x), {"x": x})
+    g = load_golden("film2_448_64")
+    m = load_sd(H.FeatureWiseLinearModulation(448, 64), g)
+    x, spk, emo = gin(g, "x.x"), gin(g, "x.spk"), gin(g, "x.emo")
+    check_all(g, m, m(x, spk, emo), {"x": x, "spk": spk, "emo": emo})
