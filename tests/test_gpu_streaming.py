@@ -167,3 +167,31 @@ def test_vocoder_trainer_checkpoint_resumes_identically(H, tmp_path):
         assert abs(la[k] - lb[k]) <= 1e-5 * max(1.0, abs(la[k])), k
     for (n, p), (_, q) in zip(a.vocoder.named_parameters(), b.vocoder.named_parameters()):
         assert float((p - q).detach().abs().max()) <= 1e-3 * max(1e-3, float(p.detach().abs().max())), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hifigan_trainer_variant_a_steps_and_checkpoints(H, tmp_path, dtype):
+    """conditioned_hifigan.py:210-299 (variant A: ONE AdamW over G + MPD + MSD; 45 L1 + 45 MSE(log-mel) + hinge per
+    sub-discriminator).  Two steps on a small model: finite loss breakdown with the reference's keys, parameters of the
+    generator AND of both discriminator families move, and save_checkpoint writes the reference's dict keys."""
+    torch.manual_seed(0)
+    model = H.ConditionedHiFiGAN(hidden_channels=64, upsample_factors=[4, 2], device="cuda").to("cuda")
+    tr = H.HiFiGANTrainer(model, learning_rate=2e-4, device="cuda")
+    torch.manual_seed(1)
+    mel = torch.randn(2, 80, 128, device="cuda").to(dtype)
+    real = torch.randn(2, 1, 1024, device="cuda").clamp(-1, 1).to(dtype)
+    spk, emo = torch.randn(2, 192, device="cuda").to(dtype), torch.randn(2, 384, device="cuda").to(dtype)
+    g0 = model.generator.generator.output_proj.weight.detach().clone()
+    p0 = model.generator.mpd.discriminators[0].conv_layers[0].weight.detach().clone()
+    s0 = model.generator.msd.discriminators[2].conv_layers[8].weight.detach().clone()
+    for _ in range(2):
+        total, parts = tr.train_step(mel, real, spk, emo)
+        assert np.isfinite(total)
+        assert all(np.isfinite(float(v.detach() if torch.is_tensor(v) else v)) for v in parts.values()) and len(parts) >= 3
+    assert float((model.generator.generator.output_proj.weight.detach() - g0).abs().max()) > 0
+    assert float((model.generator.mpd.discriminators[0].conv_layers[0].weight.detach() - p0).abs().max()) > 0
+    assert float((model.generator.msd.discriminators[2].conv_layers[8].weight.detach() - s0).abs().max()) > 0
+    path = os.path.join(tmp_path, "variant_a.pt")
+    tr.save_checkpoint(path, epoch=3, loss=total)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"} and ck["epoch"] == 3
