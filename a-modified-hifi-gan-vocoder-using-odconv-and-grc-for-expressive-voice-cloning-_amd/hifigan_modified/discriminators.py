@@ -74,6 +74,16 @@ class HiFiGANDiscriminators(nn.Module):
         self.msd = MultiScaleDiscriminator()
 
     def forward(self, real_audio: torch.Tensor, fake_audio: torch.Tensor) -> dict:
+        # discriminator step (no gradient flows into either waveform): real and fake ride through every sub-discriminator as
+        # ONE batch of 2B - half the launches, twice the grid per launch - and the outputs are split again.  Every op is
+        # per-sample, so the values are those of the two separate passes of discriminators.py:127-151.
+        if (real_audio.shape == fake_audio.shape and real_audio.dtype == fake_audio.dtype and real_audio.is_cuda
+                and torch.is_grad_enabled() and not real_audio.requires_grad and not fake_audio.requires_grad):
+            both = Fn.batch_cat(real_audio, fake_audio)
+            B = real_audio.shape[0]
+            mpd, msd = self.mpd(both), self.msd(both)
+            return {"mpd_real": [o[:B] for o in mpd], "mpd_fake": [o[B:] for o in mpd],
+                    "msd_real": [o[:B] for o in msd], "msd_fake": [o[B:] for o in msd]}
         return {
             "mpd_real": self.mpd(real_audio),
             "mpd_fake": self.mpd(fake_audio),

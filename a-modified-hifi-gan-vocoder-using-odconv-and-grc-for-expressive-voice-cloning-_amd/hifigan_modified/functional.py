@@ -368,6 +368,28 @@ class _Cat(Function):
         return tuple(outs)
 
 
+class _BatchCat(Function):
+    """torch.cat along the batch axis of two equally shaped tensors (one strided copy each); backward hands out views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = (t if t.is_contiguous() else t.contiguous() for t in (a, b))
+        out = torch.empty(2 * a.shape[0], *a.shape[1:], device=a.device, dtype=a.dtype)
+        n = a.numel()
+        ops.copy_rows(a.view(1, 1, n), out.view(2, 1, n)[0:1])
+        ops.copy_rows(b.view(1, 1, n), out.view(2, 1, n)[1:2])
+        ctx.B = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:ctx.B], g[ctx.B:]
+
+
+def batch_cat(a, b):
+    return _BatchCat.apply(a, b)
+
+
 def _grc_generic(x, blk):
     """grc_lora.py:32-68 with the parameter algebra folded: conv_g + LoRA + 1x1 -> one dense dilated conv."""
     k, d = blk.kernel_size, blk.dilation
