@@ -8,7 +8,7 @@ import hifigan_modified as H
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 Tm = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-dt = {"bf16": torch.bfloat16, "fp32": torch.float32}[sys.argv[3] if len(sys.argv) > 3 else "fp32"]
+dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[sys.argv[3] if len(sys.argv) > 3 else "fp32"]
 torch.manual_seed(0)
 voc = H.ModifiedHiFiGANVocoder()
 tr = H.VocoderTrainer(voc, device=torch.device("cuda"))
