@@ -414,6 +414,68 @@ def dropout_mask(shape, p, device):
     return (torch.rand(shape, device=device) >= p).to(torch.uint8)
 
 
+class _SplitChannels(Function):
+    """[B, sum(sizes), T] -> contiguous [B, sizes[i], T] pieces (strided copies); backward writes the pieces' gradients
+    back into one buffer."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes, ctx.shape = tuple(sizes), x.shape
+        outs, off = [], 0
+        for c in sizes:
+            o = torch.empty(x.shape[0], c, x.shape[2], device=x.device, dtype=x.dtype)
+            ops.copy_rows(x[:, off:off + c], o)
+            outs.append(o)
+            off += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        g = torch.empty(ctx.shape, device=gs[0].device, dtype=gs[0].dtype)
+        off = 0
+        for c, gi in zip(ctx.sizes, gs):
+            ops.copy_rows(gi if gi.stride(2) == 1 else gi.contiguous(), g[:, off:off + c])
+            off += c
+        return g, None
+
+
+def _mrf_merged_ok(x, blk):
+    """All branch convs AND their residual 1x1 projections read the same x: for 16-bit storage they run as ONE dense
+    'same' conv with kernel 2*max(d)+1 on the MFMA kernels (the unused taps are zero) - one launch, one data-gradient and
+    one weight-gradient GEMM per block instead of six of each, and two layout transposes instead of twenty-four."""
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    gs = list(blk.conv_layers)
+    if any(g.kernel_size != 3 or g.in_channels == g.out_channels for g in gs):
+        return False
+    return (2 * max(g.dilation for g in gs) + 1) in ops._MFMA_KS and gs[0].in_channels >= 16
+
+
+def _mrf_merged_branches(x, blk):
+    gs = list(blk.conv_layers)
+    cpd, cin = gs[0].out_channels, gs[0].in_channels
+    nb = len(gs)
+    md = max(g.dilation for g in gs)
+    kw, ctr = 2 * md + 1, md
+    folds = [_GrcFold.apply(g.conv.weight, g.conv.bias, g.lora_A, g.lora_B, g.lora_scaling, g.output_projection.weight,
+                            g.output_projection.bias, g.groups) for g in gs]
+    # parameter-sized, differentiable assembly of the merged kernel: rows [0, nb*cpd) = the folded dilated branch convs,
+    # rows [nb*cpd, 2*nb*cpd) = the residual projections (centre tap only)
+    W = folds[0][0].new_zeros(2 * nb * cpd, cin, kw)
+    bias = folds[0][1].new_zeros(2 * nb * cpd)
+    for i, (g, (w_eff, b_eff)) in enumerate(zip(gs, folds)):
+        d = g.dilation
+        for j, off in enumerate((-d, 0, d)):
+            W[i * cpd:(i + 1) * cpd, :, ctr + off] = w_eff[:, :, j]
+        bias[i * cpd:(i + 1) * cpd] = b_eff
+        W[(nb + i) * cpd:(nb + i + 1) * cpd, :, ctr] = g.residual_proj.weight[:, :, 0].to(W.dtype)
+        bias[(nb + i) * cpd:(nb + i + 1) * cpd] = g.residual_proj.bias.to(bias.dtype)
+    u = conv1d(x, W, bias, padding=md)
+    parts = _SplitChannels.apply(u, [cpd] * (2 * nb))
+    return [group_norm(parts[i], g.norm.weight, g.norm.bias, g.norm_groups, g.norm.eps, act="silu", res=parts[nb + i])
+            for i, g in enumerate(gs)]
+
+
 def mrf_block(x, blk, force_generic=False, mask=None):
     """grc_lora.py:157-163.  Inference on 64-channel blocks of the generator's shape runs the fused MFMA kernel
     (csrc/mrf_fused.hip) in channels-last layout; training and any other shape run the generic differentiable path."""
@@ -425,7 +487,7 @@ def mrf_block(x, blk, force_generic=False, mask=None):
         with torch.no_grad():
             return ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
     x = x if x.is_contiguous() else x.contiguous()
-    branches = [_grc_generic(x, g) for g in blk.conv_layers]
+    branches = _mrf_merged_branches(x, blk) if _mrf_merged_ok(x, blk) else [_grc_generic(x, g) for g in blk.conv_layers]
     cat = _Cat.apply(*branches)
     f = conv1d(cat, blk.fusion.weight, blk.fusion.bias)
     scale, p = 1.0, blk.dropout.p
