@@ -460,16 +460,26 @@ def _mrf_merged_branches(x, blk):
     folds = [_GrcFold.apply(g.conv.weight, g.conv.bias, g.lora_A, g.lora_B, g.lora_scaling, g.output_projection.weight,
                             g.output_projection.bias, g.groups) for g in gs]
     # parameter-sized, differentiable assembly of the merged kernel: rows [0, nb*cpd) = the folded dilated branch convs,
-    # rows [nb*cpd, 2*nb*cpd) = the residual projections (centre tap only)
-    W = folds[0][0].new_zeros(2 * nb * cpd, cin, kw)
-    bias = folds[0][1].new_zeros(2 * nb * cpd)
-    for i, (g, (w_eff, b_eff)) in enumerate(zip(gs, folds)):
-        d = g.dilation
-        for j, off in enumerate((-d, 0, d)):
-            W[i * cpd:(i + 1) * cpd, :, ctr + off] = w_eff[:, :, j]
-        bias[i * cpd:(i + 1) * cpd] = b_eff
-        W[(nb + i) * cpd:(nb + i + 1) * cpd, :, ctr] = g.residual_proj.weight[:, :, 0].to(W.dtype)
-        bias[(nb + i) * cpd:(nb + i + 1) * cpd] = g.residual_proj.bias.to(bias.dtype)
+    # rows [nb*cpd, 2*nb*cpd) = the residual projections (centre tap only).  One concat + one index_copy per tensor
+    # (the scatter indices are cached on the block) instead of a slice assignment per branch and tap.
+    dev = x.device
+    cache = blk.__dict__.get("_mv_merge_idx")
+    if cache is None or cache[0] != (dev, cin, cpd, kw, tuple(g.dilation for g in gs)):
+        import numpy as np
+        o, c, j = np.meshgrid(np.arange(cpd), np.arange(cin), np.arange(3), indexing="ij")
+        iw = [(((i * cpd + o) * cin + c) * kw + ctr + (j - 1) * g.dilation).reshape(-1) for i, g in enumerate(gs)]
+        o2, c2 = np.meshgrid(np.arange(cpd), np.arange(cin), indexing="ij")
+        iw += [((((nb + i) * cpd + o2) * cin + c2) * kw + ctr).reshape(-1) for i in range(nb)]
+        ib = [np.arange(i * cpd, (i + 1) * cpd) for i in range(2 * nb)]
+        cache = ((dev, cin, cpd, kw, tuple(g.dilation for g in gs)),
+                 torch.from_numpy(np.concatenate(iw)).to(dev), torch.from_numpy(np.concatenate(ib)).to(dev))
+        blk.__dict__["_mv_merge_idx"] = cache
+    _, idx_w, idx_b = cache
+    wdt = folds[0][0].dtype
+    src_w = torch.cat([f[0].reshape(-1) for f in folds] + [g.residual_proj.weight.reshape(-1).to(wdt) for g in gs])
+    src_b = torch.cat([f[1].reshape(-1) for f in folds] + [g.residual_proj.bias.reshape(-1).to(wdt) for g in gs])
+    W = src_w.new_zeros(2 * nb * cpd * cin * kw).index_copy(0, idx_w, src_w).view(2 * nb * cpd, cin, kw)
+    bias = src_b.new_zeros(2 * nb * cpd).index_copy(0, idx_b, src_b)
     u = conv1d(x, W, bias, padding=md)
     parts = _SplitChannels.apply(u, [cpd] * (2 * nb))
     return [group_norm(parts[i], g.norm.weight, g.norm.bias, g.norm_groups, g.norm.eps, act="silu", res=parts[nb + i])
