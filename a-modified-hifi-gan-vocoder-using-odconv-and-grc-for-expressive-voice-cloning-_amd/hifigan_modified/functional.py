@@ -439,6 +439,47 @@ class _SplitChannels(Function):
         return g, None
 
 
+class _BranchNorm(Function):
+    """The GroupNorm + SiLU + residual of all GRC branches of one MRF block (grc_lora.py:58-68) on the merged conv output
+    u = [v_0 .. v_{n-1} | r_0 .. r_{n-1}] (channel blocks of `cpd`): branch i is SiLU(GN_i(v_i)) + r_i, written straight into
+    channel block i of the concatenated [B, n*cpd, T] result - the kernels take channel-slice strides, so neither the split
+    nor the concat costs a copy.  params = (w_0, b_0, ..., w_{n-1}, b_{n-1}); cfg = (n, cpd, G, eps)."""
+
+    @staticmethod
+    def forward(ctx, u, cfg, *params):
+        nb, cpd, G, eps = cfg
+        u = u if u.stride(2) == 1 else u.contiguous()
+        B, _, T = u.shape
+        out = torch.empty(B, nb * cpd, T, device=u.device, dtype=u.dtype)
+        stats = []
+        for i in range(nb):
+            xs, rs = u[:, i * cpd:(i + 1) * cpd], u[:, (nb + i) * cpd:(nb + i + 1) * cpd]
+            mean, rstd = ops.groupnorm_stats(xs, G, eps)
+            ops.groupnorm_apply(xs, mean, rstd, _w(params[2 * i], u), _w(params[2 * i + 1], u), G, N.ACT_SILU, 0.1, rs,
+                                out=out[:, i * cpd:(i + 1) * cpd])
+            stats += [mean, rstd]
+        ctx.cfg = cfg
+        ctx.save_for_backward(u, *params, *stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        nb, cpd, G, eps = ctx.cfg
+        saved = ctx.saved_tensors
+        u, params, stats = saved[0], saved[1:1 + 2 * nb], saved[1 + 2 * nb:]
+        gy = gy if gy.stride(2) == 1 else gy.contiguous()
+        gu = torch.empty_like(u)
+        grads = []
+        for i in range(nb):
+            xs, gs_ = u[:, i * cpd:(i + 1) * cpd], gy[:, i * cpd:(i + 1) * cpd]
+            gx, dgw, dgb = ops.groupnorm_bwd(xs, gs_, stats[2 * i], stats[2 * i + 1], _w(params[2 * i], u), _w(params[2 * i + 1], u),
+                                             G, N.ACT_SILU, 0.1)
+            ops.copy_rows(gx, gu[:, i * cpd:(i + 1) * cpd])
+            ops.copy_rows(gs_, gu[:, (nb + i) * cpd:(nb + i + 1) * cpd])          # the residual passes the gradient through
+            grads += [_to(dgw, params[2 * i]), _to(dgb, params[2 * i + 1])]
+        return (gu, None, *grads)
+
+
 def _mrf_merged_ok(x, blk):
     """All branch convs AND their residual 1x1 projections read the same x: for 16-bit storage they run as ONE dense
     'same' conv with kernel 2*max(d)+1 on the MFMA kernels (the unused taps are zero) - one launch, one data-gradient and
@@ -481,6 +522,11 @@ def _mrf_merged_branches(x, blk):
     W = src_w.new_zeros(2 * nb * cpd * cin * kw).index_copy(0, idx_w, src_w).view(2 * nb * cpd, cin, kw)
     bias = src_b.new_zeros(2 * nb * cpd).index_copy(0, idx_b, src_b)
     u = conv1d(x, W, bias, padding=md)
+    if all(g.norm_groups == gs[0].norm_groups and g.norm.eps == gs[0].norm.eps for g in gs):
+        prm = []
+        for g in gs:
+            prm += [g.norm.weight, g.norm.bias]
+        return _BranchNorm.apply(u, (nb, cpd, gs[0].norm_groups, gs[0].norm.eps), *prm)      # already concatenated
     parts = _SplitChannels.apply(u, [cpd] * (2 * nb))
     return [group_norm(parts[i], g.norm.weight, g.norm.bias, g.norm_groups, g.norm.eps, act="silu", res=parts[nb + i])
             for i, g in enumerate(gs)]
@@ -498,7 +544,7 @@ def mrf_block(x, blk, force_generic=False, mask=None):
             return ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
     x = x if x.is_contiguous() else x.contiguous()
     branches = _mrf_merged_branches(x, blk) if _mrf_merged_ok(x, blk) else [_grc_generic(x, g) for g in blk.conv_layers]
-    cat = _Cat.apply(*branches)
+    cat = branches if torch.is_tensor(branches) else _Cat.apply(*branches)
     f = conv1d(cat, blk.fusion.weight, blk.fusion.bias)
     scale, p = 1.0, blk.dropout.p
     if training_dropout:
