@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   constexpr int ES = M::ES;
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha (KB <= OD_MAXK banks used)
-  char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
+  float* bias_l = alds + S * OD_MAXK;                          // [S][4*MW*16] alpha-mixed bias of this workgroup's rows
+  char* xl = reinterpret_cast<char*>(bias_l + S * 4 * MW * 16);
   const int RS = lds_row_stride(p.Cin * ES, ES);
 #ifdef MV_OD_TIMING
   long long tmk[8]; int ntm = 0;
@@ -179,6 +180,25 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   }
   __syncthreads();
   OD_TM();
+  // alpha-mixed bias of this workgroup's rows, once, into LDS: the K bank loads of a row are independent and overlap the first
+  // weight fetch (read one at a time in the epilogue they were serialized L2 round trips)
+  if (bias) {
+    constexpr int RWp = 4 * MW * 16;
+    for (int i = tid; i < S * RWp; i += 256) {
+      const int s = i / RWp, rr = i - s * RWp;
+      const int row = blockIdx.y * RWp + rr;
+      float v[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int o = row < p.M ? (p.transposed ? row % p.Cout : row) : 0;
+        v[kb] = ld<T>(bias + (long)(kb < p.K ? kb : 0) * p.Cout + o);
+      }
+      float a = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) a += (kb < p.K ? alds[s * OD_MAXK + kb] : 0.f) * v[kb];
+      bias_l[i] = a;
+    }
+  }
 
   float al[S][KB];
 #pragma unroll
@@ -277,10 +297,10 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
         const int r = p.transposed ? row / p.Cout : 0;
         const int o = p.transposed ? row % p.Cout : row;
         float bv[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias)
-          for (int kb = 0; kb < p.K; ++kb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] += al[s][kb] * ld<T>(bias + (long)kb * p.Cout + o + i);
+        if (bias) {
+          const f32x4 bl = *reinterpret_cast<const f32x4*>(bias_l + s * RW + (row - R0));
+          bv[0] = bl[0]; bv[1] = bl[1]; bv[2] = bl[2]; bv[3] = bl[3];
+        }
         if (film)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -600,7 +620,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
   p.nrows = NB * 16 + (p.ntaps - 1) * (p.transposed ? 1 : p.dil);
   const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
   const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
-  const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
+  const size_t lds = sizeof(float) * (S * OD_MAXK + S * 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
   auto kern = odconv_cl_kernel<T, S, MW, NB, (PFW && M::ES == 2), KB>;
   static size_t lds_set = 0;
