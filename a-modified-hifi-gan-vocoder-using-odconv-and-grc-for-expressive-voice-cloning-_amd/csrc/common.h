@@ -70,6 +70,18 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+// Activation functors for epilogue loops.  `apply_act(v, act, slope)` with a run-time `act` inside an unrolled element loop
+// compiles to a scalar branch tree PER ELEMENT (with the tanh / SiLU bodies inlined each time): kernels pick one functor
+// per launch instead - ActLrelu covers "none" (negative slope 1) and LeakyReLU branch-free, ActAny is the general case.
+struct ActLrelu {
+  float ns;
+  __device__ __forceinline__ float operator()(float v) const { return v >= 0.f ? v : v * ns; }
+};
+struct ActAny {
+  int act; float slope;
+  __device__ __forceinline__ float operator()(float v) const { return apply_act(v, act, slope); }
+};
+
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace mv

@@ -16,6 +16,7 @@
 // The x tiles of the S samples live in LDS (row stride padded by 16 B); bank weights stream from L2 in packed
 // A-fragment order (one coalesced 1 KB load per bank per fragment) and are reused for the S samples.
 #include "mfma.h"
+#include <type_traits>
 #include <cstdlib>
 #include <cstdio>
 
@@ -285,62 +286,76 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   constexpr int ORS = RW * ES + 16;                  // staged row stride (bytes)
   char* ol = xl;
   const int R0 = blockIdx.y * RW;
+  // one epilogue body per (activation kind, FiLM, pooling) combination, selected once per launch: a run-time `act` / pointer
+  // test inside the unrolled element loops compiles to scalar branch trees per element (8000 instructions before this)
+  auto epilogue = [&](auto actf, auto film_c, auto pool_c) {
+    constexpr bool HAS_FILM = decltype(film_c)::value, HAS_POOL = decltype(pool_c)::value;
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int b = b0 + s;
+    for (int s = 0; s < S; ++s) {
+      const int b = b0 + s;
 #pragma unroll
-    for (int mw = 0; mw < MW; ++mw) {
-      const int mt = mt0 + mw;
-      float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mt < n_mt && b < p.B) {
-        const int row = 16 * mt + 4 * g;
-        const int r = p.transposed ? row / p.Cout : 0;
-        const int o = p.transposed ? row % p.Cout : row;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-          const f32x4 bl = *reinterpret_cast<const f32x4*>(bias_l + s * RW + (row - R0));
-          bv[0] = bl[0]; bv[1] = bl[1]; bv[2] = bl[2]; bv[3] = bl[3];
-        }
-        if (film)
+      for (int mw = 0; mw < MW; ++mw) {
+        const int mt = mt0 + mw;
+        float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mt < n_mt && b < p.B) {
+          const int row = 16 * mt + 4 * g;
+          const int r = p.transposed ? row / p.Cout : 0;
+          const int o = p.transposed ? row % p.Cout : row;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f}, gam[4] = {1.f, 1.f, 1.f, 1.f}, bet[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias) {
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(bias_l + s * RW + (row - R0));
+            bv[0] = bl[0]; bv[1] = bl[1]; bv[2] = bl[2]; bv[3] = bl[3];
+          }
+          if (HAS_FILM)
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (o + i < p.film_F) {
-              gam[i] = ld<T>(film + (long)b * 2 * p.film_F + o + i);
-              bet[i] = ld<T>(film + (long)b * 2 * p.film_F + p.film_F + o + i);
+            for (int i = 0; i < 4; ++i)
+              if (o + i < p.film_F) {
+                gam[i] = ld<T>(film + (long)b * 2 * p.film_F + o + i);
+                bet[i] = ld<T>(film + (long)b * 2 * p.film_F + p.film_F + o + i);
+              }
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const int q = q0 + n * 16 + col;
+            const int u = p.transposed ? q * p.stride + r - p.pad : q;
+            const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+            float ov[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float vv = (acc[s][mw][n][i] + bv[i]);
+              if (HAS_FILM) vv = M::round_store(vv) * gam[i] + bet[i];   // the reference stores the conv output before FiLM
+              vv = actf(vv);
+              ov[i] = vv;
+              if (HAS_POOL && ok) rowsum[i] += M::round_store(vv);
             }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const int q = q0 + n * 16 + col;
-          const int u = p.transposed ? q * p.stride + r - p.pad : q;
-          const bool ok = q < p.nq && u >= 0 && u < p.Tout;
-          float ov[4];
+            M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+          }
+        }
+        if (HAS_POOL) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float vv = (acc[s][mw][n][i] + bv[i]);
-            if (film) vv = M::round_store(vv) * gam[i] + bet[i];   // the reference stores the conv output before FiLM
-            vv = apply_act(vv, p.act, p.slope);
-            ov[i] = vv;
-            if (ok) rowsum[i] += M::round_store(vv);
+            float v = rowsum[i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+            rowsum[i] = v;
           }
-          M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
-        }
-      }
-      if (pooled_out) {
+          if (pooled_out && col == 0 && mt < n_mt && b < p.B) {
+            const int row = 16 * mt + 4 * g;
+            const int o = p.transposed ? row % p.Cout : row;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = rowsum[i];
-#pragma unroll
-          for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-          rowsum[i] = v;
-        }
-        if (col == 0 && mt < n_mt && b < p.B) {
-          const int row = 16 * mt + 4 * g;
-          const int o = p.transposed ? row % p.Cout : row;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+            for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+          }
         }
       }
     }
+  };
+  {
+    using TT = std::true_type; using FF = std::false_type;
+    const bool simple = p.act <= ACT_LRELU;
+    const ActLrelu al_{p.act == ACT_NONE ? 1.f : p.slope};
+    const ActAny aa_{p.act, p.slope};
+    if (film) { if (simple) epilogue(al_, TT{}, TT{}); else epilogue(aa_, TT{}, TT{}); }   // FiLM only rides with pooling (input_proj)
+    else if (pooled_out) { if (simple) epilogue(al_, FF{}, TT{}); else epilogue(aa_, FF{}, TT{}); }
+    else { if (simple) epilogue(al_, FF{}, FF{}); else epilogue(aa_, FF{}, FF{}); }
   }
   OD_TM();
   __syncthreads();
