@@ -138,24 +138,25 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
   constexpr int RW = NWV * MW * 16;
   constexpr int ORS = RW * ES + 16;
   const int R0 = blockIdx.y * RW;
+  auto epi = [&](auto actf) {       // one body per activation kind: a run-time `act` in the element loop is a branch tree per element
 #pragma unroll
-  for (int mw = 0; mw < MW; ++mw) {
-    const int mt = mt0 + mw;
-    if (mt < n_mt) {
-      const int row = 16 * mt + 4 * g;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias)
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
+      if (mt < n_mt) {
+        const int row = 16 * mt + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) M::load4(bias + row, bv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = ld<T>(bias + row + i);
+        for (int n = 0; n < NB; ++n) {
+          float ov[4];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        float ov[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = apply_act(acc[mw][n][i] + bv[i], p.act, p.slope);
-        M::store4(lds + (long)(n * 16 + col) * ORS + (row - R0) * ES, ov);
+          for (int i = 0; i < 4; ++i) ov[i] = actf(acc[mw][n][i] + bv[i]);
+          M::store4(lds + (long)(n * 16 + col) * ORS + (row - R0) * ES, ov);
+        }
       }
     }
-  }
+  };
+  if (p.act <= ACT_LRELU) epi(ActLrelu{p.act == ACT_NONE ? 1.f : p.slope}); else epi(ActAny{p.act, p.slope});
   __syncthreads();
   {
     constexpr int EPC = 16 / ES;
@@ -293,24 +294,25 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
   constexpr int RW = RG * MW * 16;
   constexpr int ORS = RW * ES + 16;
   const int R0 = blockIdx.y * RW;
+  auto epi = [&](auto actf) {
 #pragma unroll
-  for (int mw = 0; mw < MW; ++mw) {
-    const int mt = mt0 + mw;
-    if (mt < n_mt) {
-      const int row = 16 * mt + 4 * g;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias)
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
+      if (mt < n_mt) {
+        const int row = 16 * mt + 4 * g;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) M::load4(bias + row, bv);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = ld<T>(bias + row + i);
+        for (int n = 0; n < NB; ++n) {
+          float ov[4];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        float ov[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ov[i] = apply_act(acc[mw][n][i] + bv[i], p.act, p.slope);
-        M::store4(lds + (long)(ps * NB * 16 + n * 16 + col) * ORS + (row - R0) * ES, ov);
+          for (int i = 0; i < 4; ++i) ov[i] = actf(acc[mw][n][i] + bv[i]);
+          M::store4(lds + (long)(ps * NB * 16 + n * 16 + col) * ORS + (row - R0) * ES, ov);
+        }
       }
     }
-  }
+  };
+  if (p.act <= ACT_LRELU) epi(ActLrelu{p.act == ACT_NONE ? 1.f : p.slope}); else epi(ActAny{p.act, p.slope});
   __syncthreads();
   {
     constexpr int EPC = 16 / ES;
