@@ -237,11 +237,23 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const T* __restrict__
     const int c = g * cg + cc;
     const float gam = gw ? ld<T>(gw + c) : 1.f;
     float a = 0.f, bsum = 0.f;
-    for (int t = threadIdx.x; t < Tn; t += blockDim.x) {
-      const float gv = ld<T>(gz + (long)b * g_bs + (long)c * g_cs + t);
-      const float xh = (ld<T>(x + (long)b * x_bs + (long)c * x_cs + t) - mu) * rs;
-      a += gv * xh;
-      bsum += gv;
+    const T* gr = gz + (long)b * g_bs + (long)c * g_cs;
+    const T* xr = x + (long)b * x_bs + (long)c * x_cs;
+    if (sizeof(T) == 2 && all_mult8(Tn, x_bs, x_cs, g_bs, g_cs) && (((uintptr_t)x | (uintptr_t)gz) & 15) == 0) {
+      for (int t = threadIdx.x * 8; t < Tn; t += blockDim.x * 8) {
+        float gv[8], xv[8];
+        load8f<T>(gr + t, gv);
+        load8f<T>(xr + t, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a += gv[e] * (xv[e] - mu) * rs; bsum += gv[e]; }
+      }
+    } else {
+      for (int t = threadIdx.x; t < Tn; t += blockDim.x) {
+        const float gv = ld<T>(gr + t);
+        const float xh = (ld<T>(xr + t) - mu) * rs;
+        a += gv * xh;
+        bsum += gv;
+      }
     }
     a = block_sum(a, red);
     bsum = block_sum(bsum, red);
@@ -263,10 +275,24 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   const float inv_n = 1.f / ((float)(C / G) * (float)Tn);
   const float s1 = s12[(b * G + g) * 2] * inv_n, s2 = s12[(b * G + g) * 2 + 1] * inv_n;
   const float gam = gw ? ld<T>(gw + c) : 1.f;
+  const T* gr = gz + (long)b * g_bs + (long)c * g_cs;
+  const T* xr = x + (long)b * x_bs + (long)c * x_cs;
+  T* or_ = gx + (long)bc * Tn;
+  if (sizeof(T) == 2 && all_mult8(Tn, x_bs, x_cs, g_bs, g_cs) && (((uintptr_t)x | (uintptr_t)gz | (uintptr_t)gx) & 15) == 0) {
+    for (int t = (blockIdx.x * blockDim.x + threadIdx.x) * 8; t < Tn; t += gridDim.x * blockDim.x * 8) {
+      float gv[8], xv[8];
+      load8f<T>(gr + t, gv);
+      load8f<T>(xr + t, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gv[e] = rs * (gv[e] * gam - s1 - (xv[e] - mu) * rs * s2);
+      store8f<T>(or_ + t, gv);
+    }
+    return;
+  }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
-    const float gv = ld<T>(gz + (long)b * g_bs + (long)c * g_cs + t);
-    const float xh = (ld<T>(x + (long)b * x_bs + (long)c * x_cs + t) - mu) * rs;
-    st<T>(gx + (long)bc * Tn + t, rs * (gv * gam - s1 - xh * s2));
+    const float gv = ld<T>(gr + t);
+    const float xh = (ld<T>(xr + t) - mu) * rs;
+    st<T>(or_ + t, rs * (gv * gam - s1 - xh * s2));
   }
 }
 
@@ -282,15 +308,38 @@ __global__ __launch_bounds__(256) void gn_pre_bwd_kernel(const T* __restrict__ x
   const float mu = mean[b * G + g], rs = rstd[b * G + g];
   const float a = rs * (gw ? ld<T>(gw + c) : 1.f);
   const float sh = (gb ? ld<T>(gb + c) : 0.f) - mu * a;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
-    float gv = ld<T>(gy + (long)b * g_bs + (long)c * g_cs + t);
-    if (mask) gv = mask[(long)bc * Tn + t] ? gv * mask_scale : 0.f;
-    const float z = ld<T>(x + (long)b * x_bs + (long)c * x_cs + t) * a + sh;
+  const T* gr = gy + (long)b * g_bs + (long)c * g_cs;
+  const T* xr = x + (long)b * x_bs + (long)c * x_cs;
+  const uint8_t* mr = mask ? mask + (long)bc * Tn : nullptr;
+  T* or_ = gz + (long)bc * Tn;
+  auto dact = [&](float z) {
     float d = 1.f;
-    if (act == ACT_SILU) { const float sg = 1.f / (1.f + __expf(-z)); d = sg * (1.f + z * (1.f - sg)); }
+    if (act == ACT_SILU) { const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z)); d = sg * (1.f + z * (1.f - sg)); }
     else if (act == ACT_LRELU) d = z >= 0.f ? 1.f : slope;
     else if (act == ACT_TANH) { const float th = tanhf(z); d = 1.f - th * th; }
-    st<T>(gz + (long)bc * Tn + t, gv * d);
+    return d;
+  };
+  if (sizeof(T) == 2 && all_mult8(Tn, x_bs, x_cs, g_bs, g_cs) && (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gz) & 15) == 0) {
+    for (int t = (blockIdx.x * blockDim.x + threadIdx.x) * 8; t < Tn; t += gridDim.x * blockDim.x * 8) {
+      float gv[8], xv[8];
+      load8f<T>(gr + t, gv);
+      load8f<T>(xr + t, xv);
+      uint2 m8 = {0u, 0u};
+      if (mr) m8 = *reinterpret_cast<const uint2*>(mr + t);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float g1 = gv[e];
+        if (mr) g1 = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) ? g1 * mask_scale : 0.f;
+        gv[e] = g1 * dact(xv[e] * a + sh);
+      }
+      store8f<T>(or_ + t, gv);
+    }
+    return;
+  }
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
+    float gv = ld<T>(gr + t);
+    if (mr) gv = mr[t] ? gv * mask_scale : 0.f;
+    st<T>(or_ + t, gv * dact(ld<T>(xr + t) * a + sh));
   }
 }
 
@@ -519,7 +568,9 @@ extern "C" int mv_groupnorm_bwd(const void* x, const void* gy, const float* mean
   float* dgb_bc = dgw_bc + (size_t)B * C;  // [B*C]
   const long dense_bs = (long)C * T_, dense_cs = T_;
   MV_DISPATCH(dtype, {
-    dim3 ge(grid_for(T_, 256, 64), B * C);
+    const bool vec = sizeof(T) == 2 && all_mult8(T_, x_bs, x_cs, g_bs, g_cs) &&
+                     (((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gz_ws | (uintptr_t)gx) & 15) == 0;
+    dim3 ge(grid_for(vec ? cdiv(T_, 8) : T_, 256, 64), B * C);
     hipLaunchKernelGGL(gn_pre_bwd_kernel<T>, ge, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, mean, rstd,
                        (const T*)gw, (const T*)gb, mask, mask_scale, (T*)gz_ws, C, T_, G, act, slope, x_bs, x_cs, g_bs, g_cs);
     hipLaunchKernelGGL(gn_bwd_stats_kernel<T>, dim3(B * G), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gz_ws,

@@ -70,6 +70,23 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   }
 }
 
+// 8 consecutive 16-bit elements <-> 8 floats through one 16-byte access (p must be 16-byte aligned; T is bf16 or f16)
+template <typename T> __device__ __forceinline__ void load8f(const T* p, float* o) {
+  alignas(16) T tmp[8];
+  *reinterpret_cast<uint4*>(tmp) = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = ld<T>(tmp + e);
+}
+template <typename T> __device__ __forceinline__ void store8f(T* p, const float* v) {
+  alignas(16) T tmp[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) st<T>(tmp + e, v[e]);
+  *reinterpret_cast<uint4*>(p) = *reinterpret_cast<uint4*>(tmp);
+}
+__host__ __device__ inline bool all_mult8(long a, long b = 0, long c2 = 0, long d = 0, long e = 0, long f = 0, long g = 0) {
+  return ((a | b | c2 | d | e | f | g) & 7) == 0;
+}
+
 // Activation functors for epilogue loops.  `apply_act(v, act, slope)` with a run-time `act` inside an unrolled element loop
 // compiles to a scalar branch tree PER ELEMENT (with the tanh / SiLU bodies inlined each time): kernels pick one functor
 // per launch instead - ActLrelu covers "none" (negative slope 1) and LeakyReLU branch-free, ActAny is the general case.

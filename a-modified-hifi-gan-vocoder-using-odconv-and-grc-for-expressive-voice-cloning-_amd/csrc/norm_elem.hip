@@ -249,12 +249,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const T* rr = res ? res + (long)b * r_bs + (long)c * r_cs : nullptr;
   const uint8_t* mr = mask ? mask + (long)bc * Tn : nullptr;
   T* yr = y + (long)b * y_bs + (long)c * y_cs;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
-    float v = apply_act(ld<T>(xr + t) * a + sh, act, slope);
-    if (mr) v = mr[t] ? v * mask_scale : 0.f;
-    if (rr) v += ld<T>(rr + t);
-    st<T>(yr + t, v);
-  }
+  // 16-bit rows that allow it move 16 bytes per thread and access; the activation is chosen once (functor), not per element
+  const bool vec = sizeof(T) == 2 && all_mult8(Tn, x_bs, x_cs, r_bs, r_cs, y_bs, y_cs) &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0;
+  auto body = [&](auto actf) {
+    if (vec) {
+      for (int t = (blockIdx.x * blockDim.x + threadIdx.x) * 8; t < Tn; t += gridDim.x * blockDim.x * 8) {
+        float v[8], r8[8];
+        load8f<T>(xr + t, v);
+        if (rr) load8f<T>(rr + t, r8);
+        uint2 m8 = {0u, 0u};
+        if (mr) m8 = *reinterpret_cast<const uint2*>(mr + t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float w = actf(v[e] * a + sh);
+          if (mr) w = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) ? w * mask_scale : 0.f;
+          if (rr) w += r8[e];
+          v[e] = w;
+        }
+        store8f<T>(yr + t, v);
+      }
+    } else {
+      for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < Tn; t += gridDim.x * blockDim.x) {
+        float v = actf(ld<T>(xr + t) * a + sh);
+        if (mr) v = mr[t] ? v * mask_scale : 0.f;
+        if (rr) v += ld<T>(rr + t);
+        st<T>(yr + t, v);
+      }
+    }
+  };
+  if (act <= ACT_LRELU) body(ActLrelu{act == ACT_NONE ? 1.f : slope}); else body(ActAny{act, slope});
 }
 
 // ---------------------------------------------------------------- FiLM / scale-shift / activations
@@ -452,7 +476,10 @@ extern "C" int mv_groupnorm_apply(const void* x, const float* mean, const float*
                                   int T_, int G, int act, float slope, long x_bs, long x_cs, long r_bs, long r_cs,
                                   long y_bs, long y_cs, int dtype, void* stream) {
   MV_CHECK_ARG(x && mean && rstd && y && B > 0 && C > 0 && T_ > 0 && G > 0 && C % G == 0 && (long)B * C <= 65535);
-  dim3 grid(grid_for(T_, 256, 64), B * C);
+  // 16-bit rows that qualify for the 16-byte path (same test as in the kernel) need 8x fewer threads along T
+  const bool vec = dtype != MV_F32 && all_mult8(T_, x_bs, x_cs, r_bs, r_cs, y_bs, y_cs) &&
+                   (((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0;
+  dim3 grid(grid_for(vec ? cdiv(T_, 8) : T_, 256, 64), B * C);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(gn_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, mean,
                                         rstd, (const T*)gw, (const T*)gb, (const T*)res, mask, mask_scale, (T*)y, C,
                                         T_, G, act, slope, x_bs, x_cs, r_bs, r_cs, y_bs, y_cs));
