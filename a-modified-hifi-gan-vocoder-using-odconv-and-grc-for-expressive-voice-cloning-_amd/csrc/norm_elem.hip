@@ -359,6 +359,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
     if (c0 + i < Cn && r0 + tx < ldy) st<T>(y + by + (long)(c0 + i) * ldy + r0 + tx, tile[tx][i]);
 }
 
+// 16-bit variant: 64 x 64 tiles, every global access is 16 bytes (8 elements) along the contiguous axis of its tensor;
+// the tile is transposed through LDS with 2-byte writes.  Requires Cn, ldx, ldy multiples of 8 and 16-byte aligned bases.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose16_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int Cn, int ldx, int ldy,
+                                                          long x_bs, long y_bs) {
+  __shared__ unsigned short tile[64][64 + 8];          // [col of x][row of x], padded rows
+  const long bx = (long)blockIdx.z * x_bs, by = (long)blockIdx.z * y_bs;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * 256;                      // 512 chunks: row = idx / 8, chunk = idx % 8
+    const int rr = idx >> 3, ch = idx & 7;
+    uint4 v = {0u, 0u, 0u, 0u};
+    if (r0 + rr < R && c0 + ch * 8 < Cn) v = *reinterpret_cast<const uint4*>(x + bx + (long)(r0 + rr) * ldx + c0 + ch * 8);
+    const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[ch * 8 + j][rr] = e[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid + k * 256;                      // output row = column c of x, 8 chunks of 8 x-rows each
+    const int cc = idx >> 3, ch = idx & 7;
+    if (c0 + cc < Cn && r0 + ch * 8 < ldy)
+      *reinterpret_cast<uint4*>(y + by + (long)(c0 + cc) * ldy + r0 + ch * 8) = *reinterpret_cast<const uint4*>(&tile[cc][ch * 8]);
+  }
+}
+
 template <typename S, typename D>
 __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ x, D* __restrict__ y, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -541,6 +570,13 @@ static int transpose_launch(const void* x, void* y, int batch, int R, int Cn, in
   MV_CHECK_ARG(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0 && ldx >= Cn && ldy >= R && cdiv(ldy, 32) <= 65535);
   if (x_bs < 0) x_bs = (long)R * ldx;
   if (y_bs < 0) y_bs = (long)Cn * ldy;
+  if (dtype != MV_F32 && all_mult8(Cn, ldx, ldy, x_bs, y_bs) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    dim3 grid(cdiv(Cn, 64), cdiv(ldy, 64), batch);
+    if (dtype == MV_BF16) hipLaunchKernelGGL(transpose16_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, R, Cn, ldx, ldy, x_bs, y_bs);
+    else hipLaunchKernelGGL(transpose16_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y, R, Cn, ldx, ldy, x_bs, y_bs);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   dim3 grid(cdiv(Cn, 32), cdiv(ldy, 32), batch);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(transpose_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                         (T*)y, R, Cn, ldx, ldy, x_bs, y_bs));
