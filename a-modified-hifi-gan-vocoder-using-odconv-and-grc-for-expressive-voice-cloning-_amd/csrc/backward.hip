@@ -416,6 +416,15 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const T* __restrict__ src, 
   const int r = blockIdx.y, outer = r / rows_inner, inner = r % rows_inner;
   const T* s = src + outer * s_os + inner * s_rs;
   T* d = dst + outer * d_os + inner * d_rs;
+  // whole 16-byte pieces when the row geometry allows it (bytes: the element type does not matter for a copy)
+  constexpr int EPV = 16 / sizeof(T);
+  if (n % EPV == 0 && s_rs % EPV == 0 && d_rs % EPV == 0 && s_os % EPV == 0 && d_os % EPV == 0 &&
+      (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n / EPV; i += gridDim.x * blockDim.x) d4[i] = s4[i];
+    return;
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
 }
 
@@ -616,7 +625,10 @@ extern "C" int mv_avgpool1d_bwd(const void* gy, void* gx, long rows, int T_, int
 extern "C" int mv_copy2d(const void* src, void* dst, int n, int rows_outer, int rows_inner, long s_os, long s_rs, long d_os,
                          long d_rs, int dtype, void* stream) {
   MV_CHECK_ARG(src && dst && n > 0 && rows_outer > 0 && rows_inner > 0 && (long)rows_outer * rows_inner <= 65535);
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(copy2d_kernel<T>, dim3(grid_for(n, 256, 64), rows_outer * rows_inner), dim3(256), 0,
+  const int epv = dtype == MV_F32 ? 4 : 8;
+  const bool vec = n % epv == 0 && s_rs % epv == 0 && d_rs % epv == 0 && s_os % epv == 0 && d_os % epv == 0 &&
+                   (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(copy2d_kernel<T>, dim3(grid_for(vec ? n / epv : n, 256, 64), rows_outer * rows_inner), dim3(256), 0,
                                         (hipStream_t)stream, (const T*)src, (T*)dst, n, s_rs, d_rs, rows_inner, s_os, d_os));
   MV_LAUNCH_CHECK();
   return MV_OK;
