@@ -20,6 +20,7 @@
 // staged once per workgroup.
 #include "mfma.h"
 #include <cstring>
+#include <type_traits>
 #include <cstdio>
 
 namespace mv {
@@ -465,28 +466,33 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
     // ---- stage 4 (pass 3): out = GN8(f) * keep/(1-p) + x, written IN PLACE over this wave's x tile, then streamed
     //      to HBM as whole 128/256-byte rows (16 B per lane, 1 KB per wave instruction)
+    // the dropout-mask test is hoisted out of the 64-element loop (inference passes no mask)
+    auto stage4 = [&](auto mask_c) {
+      constexpr bool HAS_MASK = decltype(mask_c)::value;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int q = 2 * m + (g >> 1);
-      const float mu = st8[q * 2], rs = st8[q * 2 + 1];
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(g8 + 16 * m + 4 * g);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(be8 + 16 * m + 4 * g);
+      for (int m = 0; m < 4; ++m) {
+        const int q = 2 * m + (g >> 1);
+        const float mu = st8[q * 2], rs = st8[q * 2 + 1];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g8 + 16 * m + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(be8 + 16 * m + 4 * g);
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) {
-        const int t = t0 + n * 16 + col;
-        char* cell = xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES;
-        float xr[4], o[4];
-        M::load4(cell, xr);
+        for (int n = 0; n < NTW; ++n) {
+          const int t = t0 + n * 16 + col;
+          char* cell = xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES;
+          float xr[4], o[4];
+          M::load4(cell, xr);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = rs * ga[r];
-          float w = f[m][n][r] * sc + (be[r] - mu * sc);
-          if (mask) w = (t < Tn && mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r]) ? w * mask_scale : 0.f;
-          o[r] = w + xr[r];
+          for (int r = 0; r < 4; ++r) {
+            const float sc = rs * ga[r];
+            float w = f[m][n][r] * sc + (be[r] - mu * sc);
+            if (HAS_MASK) w = (t < Tn && mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r]) ? w * mask_scale : 0.f;
+            o[r] = w + xr[r];
+          }
+          M::store4(cell, o);
         }
-        M::store4(cell, o);
       }
-    }
+    };
+    if (mask) stage4(std::true_type{}); else stage4(std::false_type{});
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < (TW * CH) / 64; ++i) {
