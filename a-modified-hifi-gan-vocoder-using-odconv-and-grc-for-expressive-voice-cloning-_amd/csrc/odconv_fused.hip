@@ -540,48 +540,62 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   constexpr int ORS = RW * ES + 16;
   char* ol = xl;
   const int R0 = blockIdx.x * RW;
+  auto epilogue = [&](auto actf, auto pool_c) {      // one body per (activation, pooling): no per-element branch trees
+    constexpr bool HAS_POOL = decltype(pool_c)::value;
 #pragma unroll
-  for (int s = 0; s < S; ++s) {
-    const int b = b0 + s;
-    float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
-    if (mt < n_mt && b < p.B) {
-      const int row = 16 * mt + 4 * g;
-      const int r = p.transposed ? row / p.Cout : 0;
-      const int o = p.transposed ? row % p.Cout : row;
-      float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (bias)
-        for (int k2 = 0; k2 < p.K; ++k2)
+    for (int s = 0; s < S; ++s) {
+      const int b = b0 + s;
+      float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mt < n_mt && b < p.B) {
+        const int row = 16 * mt + 4 * g;
+        const int r = p.transposed ? row / p.Cout : 0;
+        const int o = p.transposed ? row % p.Cout : row;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {                                   // bank biases of these 4 channels: independent 8-byte loads, then the alpha mix
+          float braw[KB][4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) bv[i] += alds[s * OD_MAXK + k2] * ld<T>(bias + (long)k2 * p.Cout + o + i);
+          for (int k2 = 0; k2 < KB; ++k2) M::load4(bias + (long)(k2 < p.K ? k2 : 0) * p.Cout + o, braw[k2]);
 #pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        const int q = n * 16 + col;
-        const int u = p.transposed ? q * p.stride + r - p.pad : q;
-        const bool ok = q < p.nq && u >= 0 && u < p.Tout;
-        float ov[4];
+          for (int k2 = 0; k2 < KB; ++k2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] += (k2 < p.K ? alds[s * OD_MAXK + k2] : 0.f) * braw[k2][i];
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int q = n * 16 + col;
+          const int u = p.transposed ? q * p.stride + r - p.pad : q;
+          const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+          float ov[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            ov[i] = actf(out[s][n][i] + bv[i]);
+            if (HAS_POOL && ok) rowsum[i] += M::round_store(ov[i]);
+          }
+          M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+        }
+      }
+      if (HAS_POOL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          ov[i] = apply_act(out[s][n][i] + bv[i], p.act, p.slope);
-          if (ok) rowsum[i] += M::round_store(ov[i]);
+          float v = rowsum[i];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+          rowsum[i] = v;
         }
-        M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+        if (col == 0 && mt < n_mt && b < p.B) {
+          const int row = 16 * mt + 4 * g;
+          const int o = p.transposed ? row % p.Cout : row;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+        }
       }
     }
-    if (pooled_out) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = rowsum[i];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-        rowsum[i] = v;
-      }
-      if (col == 0 && mt < n_mt && b < p.B) {
-        const int row = 16 * mt + 4 * g;
-        const int o = p.transposed ? row % p.Cout : row;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
-      }
-    }
+  };
+  {
+    const ActLrelu al_{p.act == ACT_NONE ? 1.f : p.slope};
+    const ActAny aa_{p.act, p.slope};
+    if (pooled_out) { if (p.act <= ACT_LRELU) epilogue(al_, std::true_type{}); else epilogue(aa_, std::true_type{}); }
+    else { if (p.act <= ACT_LRELU) epilogue(al_, std::false_type{}); else epilogue(aa_, std::false_type{}); }
   }
   __syncthreads();
   {
