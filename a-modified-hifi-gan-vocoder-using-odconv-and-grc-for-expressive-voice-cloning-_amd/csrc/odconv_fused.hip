@@ -362,18 +362,21 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   {
     constexpr int EPC = 16 / ES;                     // elements per 16-byte chunk
     constexpr int CPR = RW / EPC;                    // chunks per staged row
-    const int total = S * NB * 16 * CPR;
-    for (int i = tid; i < total; i += 256) {
-      const int ch = i % CPR, qi = (i / CPR) % (NB * 16), s = i / (CPR * NB * 16);
-      const int b = b0 + s, q = q0 + qi, row = R0 + ch * EPC;
-      if (b >= p.B || q >= p.nq || row >= p.M) continue;
-      const int r = p.transposed ? row / p.Cout : 0;
-      const int o = p.transposed ? row % p.Cout : row;
-      const int u = p.transposed ? q * p.stride + r - p.pad : q;
-      if (u < 0 || u >= p.Tout) continue;
-      const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)(s * NB * 16 + qi)) * ORS + ch * 16);
-      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
-    }
+    // a thread keeps its 16-byte column of the staged rows (256 % CPR == 0): the phase / channel split of that column - two
+    // integer divisions by the run-time Cout - is done once, not once per row
+    static_assert(256 % CPR == 0, "store loop: fixed column per thread");
+    const int ch = tid % CPR, row = R0 + ch * EPC;
+    const int r = p.transposed ? row / p.Cout : 0;
+    const int o = p.transposed ? row % p.Cout : row;
+    if (row < p.M)
+      for (int e = tid / CPR; e < S * NB * 16; e += 256 / CPR) {
+        const int s = e / (NB * 16), qi = e - s * (NB * 16);
+        const int b = b0 + s, q = q0 + qi;
+        const int u = p.transposed ? q * p.stride + r - p.pad : q;
+        if (b >= p.B || q >= p.nq || u < 0 || u >= p.Tout) continue;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)e) * ORS + ch * 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
+      }
   }
 #ifdef MV_OD_TIMING
   OD_TM();
@@ -601,18 +604,19 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   {
     constexpr int EPC = 16 / ES;
     constexpr int CPR = RW / EPC;
-    const int totalc = S * NB * 16 * CPR;
-    for (int i = tid; i < totalc; i += 256) {
-      const int ch = i % CPR, qi = (i / CPR) % (NB * 16), s = i / (CPR * NB * 16);
-      const int b = b0 + s, row = R0 + ch * EPC;
-      if (b >= p.B || qi >= p.nq || row >= p.M) continue;
-      const int r = p.transposed ? row / p.Cout : 0;
-      const int o = p.transposed ? row % p.Cout : row;
-      const int u = p.transposed ? qi * p.stride + r - p.pad : qi;
-      if (u < 0 || u >= p.Tout) continue;
-      const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)(s * NB * 16 + qi)) * ORS + ch * 16);
-      *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
-    }
+    static_assert(256 % CPR == 0, "store loop: fixed column per thread");
+    const int ch = tid % CPR, row = R0 + ch * EPC;
+    const int r = p.transposed ? row / p.Cout : 0;
+    const int o = p.transposed ? row % p.Cout : row;
+    if (row < p.M)
+      for (int e = tid / CPR; e < S * NB * 16; e += 256 / CPR) {
+        const int s = e / (NB * 16), qi = e - s * (NB * 16);
+        const int b = b0 + s;
+        const int u = p.transposed ? qi * p.stride + r - p.pad : qi;
+        if (b >= p.B || qi >= p.nq || u < 0 || u >= p.Tout) continue;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)e) * ORS + ch * 16);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
+      }
   }
 }
 
