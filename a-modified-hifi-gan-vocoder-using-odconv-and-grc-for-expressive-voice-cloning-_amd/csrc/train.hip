@@ -7,6 +7,32 @@
 
 namespace mv {
 
+// ------------------------------------------------------------------------------------------- dropout keep-mask (Philox4x32-10)
+// mask[i] = 1 with probability 1-p (nn.Dropout of grc_lora.py:151,162).  Counter-based: element block i/8 is counter (i/8, 0, 0, 0)
+// under key (seed lo, seed hi), 16 random bits per element - the mask depends only on (seed, index), not on the launch geometry.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, long n, uint32_t thresh16, uint32_t k0, uint32_t k1) {
+  const long nblk = (n + 7) / 8;
+  for (long blk = (long)blockIdx.x * blockDim.x + threadIdx.x; blk < nblk; blk += (long)gridDim.x * blockDim.x) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0u, 0u, k0, k1, r);
+    uint8_t m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = ((r[e >> 1] >> (16 * (e & 1))) & 0xffffu) >= thresh16 ? 1 : 0;   // keep iff u >= p
+    if (blk * 8 + 8 <= n) *reinterpret_cast<uint2*>(mask + blk * 8) = *reinterpret_cast<const uint2*>(m);
+    else for (int e = 0; blk * 8 + e < n; ++e) mask[blk * 8 + e] = m[e];
+  }
+}
+
 // ------------------------------------------------------------------------------------------- GRC fold backward
 // forward (norm_elem.hip grc_fold_kernel): comb[o'][c][j] = [c in grp(o')] Wc[o'][c_loc][j] + [j==mid] s (A B)[c][o']
 //   w_eff[o][c][j] = sum_o' Wp[o][o'] comb[o'][c][j];  b_eff[o] = sum_o' Wp[o][o'] bc[o'] + bp[o]
@@ -257,6 +283,17 @@ using namespace mv;
 static inline int grid_for(long n, int block = 256, int cap = 2048) {
   long g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+extern "C" int mv_dropout_mask(uint8_t* mask, long n, float p, long seed_, void* stream) {
+  const uint64_t seed = (uint64_t)seed_;
+  MV_CHECK_ARG(mask && n > 0 && p >= 0.f && p < 1.f && ((uintptr_t)mask & 7) == 0);
+  const uint32_t thresh = (uint32_t)(p * 65536.f + 0.5f);
+  const long nblk = (n + 7) / 8;
+  const unsigned grid = (unsigned)((nblk + 255) / 256 > 4096 ? 4096 : (nblk + 255) / 256);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, n, thresh, (uint32_t)seed, (uint32_t)(seed >> 32));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
 }
 
 extern "C" int mv_grc_fold_bwd(const float* g_weff, const float* g_beff, const void* conv_w, const void* conv_b,

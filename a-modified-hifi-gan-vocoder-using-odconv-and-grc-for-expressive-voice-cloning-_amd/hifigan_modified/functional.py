@@ -410,8 +410,13 @@ def grc_lora_block(x, blk, out=None, out_channel_offset=0):
 
 
 def dropout_mask(shape, p, device):
-    """uint8 keep-mask of nn.Dropout(p) (grc_lora.py:151,162); drawn from torch's Philox stream of this rank."""
-    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+    """uint8 keep-mask of nn.Dropout(p) (grc_lora.py:151,162) from our own Philox4x32-10 kernel; the 64-bit key of each mask is
+    drawn from torch's CPU generator, so `torch.manual_seed` (per rank) fixes the whole dropout stream."""
+    from ctypes import c_void_p
+    mask = torch.empty(shape, device=device, dtype=torch.uint8)
+    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    N.call("mv_dropout_mask", c_void_p(mask.data_ptr()), mask.numel(), float(p), seed, ops._stream())
+    return mask
 
 
 class _SplitChannels(Function):

@@ -387,3 +387,53 @@ def test_mrf_merged_conv_training_path_vs_fp64_oracle(H, dtype, args, kw, T):
         # leaves 10 % in fp16 and 24 % in bf16 (measured identically on the per-branch path, so it is rounding, not the merge)
         tol = (0.5 if dtype == torch.bfloat16 else 0.2) if ref.numel() == 1 else (3 * eps if "lora" in k else eps)
         assert O.rel_l2(p.grad.cpu(), ref) < tol, (k, O.rel_l2(p.grad.cpu(), ref))
+
+
+def _philox4x32_10_np(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11) on uint32 numpy arrays: the published algorithm, restated here as the test's checker."""
+    c = [np.asarray(v, dtype=np.uint64) for v in ctr]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M = np.uint64(0xffffffff)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return [v.astype(np.uint32) for v in c]
+
+
+def test_philox_restatement_known_answers():
+    # Random123 kat_vectors: philox4x32 10 rounds.
+    z = _philox4x32_10_np([[0], [0], [0], [0]], (0, 0))
+    assert [int(v[0]) for v in z] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xffffffff
+    z = _philox4x32_10_np([[f], [f], [f], [f]], (f, f))
+    assert [int(v[0]) for v in z] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    z = _philox4x32_10_np([[0x243f6a88], [0x85a308d3], [0x13198a2e], [0x03707344]], (0xa4093822, 0x299f31d0))
+    assert [int(v[0]) for v in z] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+@pytest.mark.parametrize("n,p", [(8 * 4096 + 5, 0.1), (3, 0.5), (1 << 20, 0.25), (64, 0.0)])
+def test_dropout_mask_kernel_is_philox_bit_exact(H, n, p):
+    """mv_dropout_mask: bit-exact against the numpy Philox restatement (counter = index/8, 16 bits per element)."""
+    import ctypes
+    seed = 0x1234567_89abcdef
+    m = torch.empty(n, device="cuda", dtype=torch.uint8)
+    from hifigan_modified import _native as N_, ops as ops_
+    N_.call("mv_dropout_mask", ctypes.c_void_p(m.data_ptr()), n, float(p), seed, ops_._stream())
+    nblk = (n + 7) // 8
+    blk = np.arange(nblk, dtype=np.uint64)
+    r = _philox4x32_10_np([blk & np.uint64(0xffffffff), blk >> np.uint64(32), np.zeros(nblk), np.zeros(nblk)],
+                          (seed & 0xffffffff, seed >> 32))
+    u16 = np.stack([(r[e >> 1] >> np.uint32(16 * (e & 1))) & np.uint32(0xffff) for e in range(8)], axis=1).reshape(-1)[:n]
+    ref = (u16 >= np.uint32(int(p * 65536 + 0.5))).astype(np.uint8)
+    assert np.array_equal(m.cpu().numpy(), ref)
+    if n >= 1 << 20:
+        assert abs(ref.mean() - (1 - p)) < 3e-3
+
+
+def test_dropout_mask_follows_torch_manual_seed(H):
+    from hifigan_modified import functional as F_
+    torch.manual_seed(7); a = F_.dropout_mask((4, 64, 100), 0.1, "cuda"); b = F_.dropout_mask((4, 64, 100), 0.1, "cuda")
+    torch.manual_seed(7); a2 = F_.dropout_mask((4, 64, 100), 0.1, "cuda")
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    assert abs(a.float().mean().item() - 0.9) < 0.02
