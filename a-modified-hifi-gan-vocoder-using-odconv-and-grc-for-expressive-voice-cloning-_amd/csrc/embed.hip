@@ -1,0 +1,481 @@
+// Conditioning producers: the kernels of the ECAPA-TDNN speaker encoder and the Emotion2Vec
+// emotion encoder (reference embedding_extractors.py:13-284) that are not plain convolutions.  Activations are channels-last
+// [B][T][C]; every Conv1d / Linear over them runs on the MFMA implicit-GEMM kernels of disc_fused.hip (BatchNorm folded into
+// the packed weights on the host side, ReLU / tanh in the conv epilogue).  Here:
+//   mha_kernel            multi-head self-attention (flash form, online softmax, S^T = K Q^T and O^T = V^T P^T on MFMA: the
+//                         accumulator layout of S^T IS the B-operand layout of P^T, so the probabilities never leave registers)
+//   add_layernorm_kernel  y = LayerNorm(x + r) (post-norm transformer layer)
+//   mean_t_kernel         mean over time -> fp32 [B][C]                     (SE squeeze, utterance pooling)
+//   se_gate_kernel        sigmoid(W2 relu(W1 m + b1) + b2)                  (SE excitation, embedding_extractors.py:159-170)
+//   scale_add_kernel      y = x * gate[b][c] + r                            (SE scale + block residual, :147-149)
+//   res2_glue_kernel      cat[:, i] = y_i ; next input = u[:, i+1] + y_i    (Res2Net chain, :135-143)
+//   asp_* kernels         softmax over CHANNELS (as the reference has it, :44), attended mean / unbiased std over time (:76-84)
+//   l2norm_rows_kernel    F.normalize(p=2, dim=1)                           (:90, :245)
+#include "common.h"
+#include "mfma.h"
+
+namespace mv {
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* o) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+    load8f<T>(p, o);
+  }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* v) {
+  if constexpr (sizeof(T) == 4) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    store8f<T>(p, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- y = LN(x + r) * g + b
+// One wave per row; C % 8 == 0; the row (<= 8 x 8 x 64 = 4096 channels) stays in registers between the two passes.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ r, const float* __restrict__ gam,
+                                                            const float* __restrict__ bet, T* __restrict__ y, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[NV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < C) {
+      load8<T>(x + row * C + c, v[i]);
+      if (r) { float t[8]; load8<T>(r + row * C + c, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] += t[e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 8;
+    if (c < C) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rstd * gam[c + e] + bet[c + e];
+      store8<T>(y + row * C + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- mean over time
+// x [B][T][C] -> out fp32 [B][C].  grid (C/64, B, TS): thread = (channel, time slice); TS slices combined by atomics when > 1.
+template <typename T>
+__global__ __launch_bounds__(256) void mean_t_kernel(const T* __restrict__ x, float* __restrict__ out, int T_, int C, float inv_t) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sl = threadIdx.x >> 6;                       // 4 time slices per block
+  const int b = blockIdx.y;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (c < C)
+    for (int t = sl; t < T_; t += 4) s += ld<T>(x + ((long)b * T_ + t) * C + c);
+  red[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) out[(long)b * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * inv_t;
+}
+
+// ------------------------------------------------------------------------------------------- SE excitation
+// gate[b][c] = sigmoid(W2[c][:] . relu(W1 m_b + b1) + b2[c]);  W1 [R][C], W2 [C][R] fp32 masters; one block per sample.
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate,
+                                                      int C, int R) {
+  extern __shared__ float sm[];                          // m_b [C] | h [R]
+  float* ml = sm; float* hl = sm + C;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += 256) ml[c] = m[(long)b * C + c];
+  __syncthreads();
+  for (int r = wid; r < R; r += 4) {                     // one wave per hidden unit
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += w1[(long)r * C + c] * ml[c];
+    s = wave_sum(s);
+    if (lane == 0) hl[r] = fmaxf(s + b1[r], 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = b2[c];
+    for (int r = 0; r < R; ++r) s += w2[(long)c * R + r] * hl[r];
+    gate[(long)b * C + c] = 1.f / (1.f + __expf(-s));
+  }
+}
+
+// ------------------------------------------------------------------------------------------- y = x * gate[b][c] + r
+template <typename T>
+__global__ __launch_bounds__(256) void scale_add_kernel(const T* __restrict__ x, const float* __restrict__ gate, const T* __restrict__ r,
+                                                        T* __restrict__ y, long n8, int T_, int C) {
+  const int c8 = C / 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c8) * 8;
+    const long b = i / ((long)c8 * T_);
+    float v[8], rr[8];
+    load8<T>(x + i * 8, v);
+    load8<T>(r + i * 8, rr);
+    const float* g = gate + b * C + c;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * g[e] + rr[e];
+    store8<T>(y + i * 8, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- Res2Net chain glue
+// cat[row][dst_off .. +cs) = src[row][0..cs)  (src = u slice 0 at src_stride C for the first step, else the conv output);
+// nxt[row][0..cs) = u[row][nxt_off .. +cs) + src[row][..]   when nxt != nullptr.   cs % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void res2_glue_kernel(const T* __restrict__ src, int src_stride, const T* __restrict__ u, T* __restrict__ cat,
+                                                        T* __restrict__ nxt, long rows, int C, int cs, int dst_off, int nxt_off) {
+  const int p8 = cs / 8;
+  const long n = rows * p8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long row = i / p8;
+    const int c = (int)(i % p8) * 8;
+    float v[8];
+    load8<T>(src + row * src_stride + c, v);
+    store8<T>(cat + row * C + dst_off + c, v);
+    if (nxt) {
+      float w[8];
+      load8<T>(u + row * C + nxt_off + c, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[e] += v[e];
+      store8<T>(nxt + row * cs + c, w);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- attentive statistics pooling
+// Phase 1: per (b,t) row, softmax statistics of the logits over the C channels: stat[row] = (max, 1/sum exp).
+template <typename T>
+__global__ __launch_bounds__(256) void asp_rowstat_kernel(const T* __restrict__ lg, float2* __restrict__ stat, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float m = -3.0e38f;
+  for (int c = lane * 8; c < C; c += 512) { float v[8]; load8<T>(lg + row * C + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, v[e]); }
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane * 8; c < C; c += 512) { float v[8]; load8<T>(lg + row * C + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += __expf(v[e] - m); }
+  s = wave_sum(s);
+  if (lane == 0) stat[row] = make_float2(m, 1.f / s);
+}
+// Phase 2: per (b,c): a_t = x * softmax weight; pooled[b][c] = mean_t a, pooled[b][C + c] = unbiased std_t a (two passes over t).
+template <typename T>
+__global__ __launch_bounds__(256) void asp_pool_kernel(const T* __restrict__ x, const T* __restrict__ lg, const float2* __restrict__ stat,
+                                                       float* __restrict__ pooled, int T_, int C) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6, b = blockIdx.y;
+  __shared__ float red[4][64];
+  const bool ok = c < C;
+  float s = 0.f;
+  if (ok)
+    for (int t = sl; t < T_; t += 4) {
+      const long row = (long)b * T_ + t;
+      const float2 st_ = stat[row];
+      s += ld<T>(x + row * C + c) * __expf(ld<T>(lg + row * C + c) - st_.x) * st_.y;
+    }
+  red[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / (float)T_;
+  __syncthreads();
+  float q = 0.f;
+  if (ok)
+    for (int t = sl; t < T_; t += 4) {
+      const long row = (long)b * T_ + t;
+      const float2 st_ = stat[row];
+      const float d = ld<T>(x + row * C + c) * __expf(ld<T>(lg + row * C + c) - st_.x) * st_.y - mean;
+      q += d * d;
+    }
+  red[sl][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (sl == 0 && ok) {
+    const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)(T_ - 1);
+    pooled[(long)b * 2 * C + c] = mean;
+    pooled[(long)b * 2 * C + C + c] = sqrtf(var);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- rows / max(||row||, eps)
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, T* __restrict__ y, int C, float eps) {
+  __shared__ float red[16];
+  const long b = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) { const float v = x[b * C + c]; s += v * v; }
+  s = block_sum(s, red);
+  const float inv = 1.f / fmaxf(sqrtf(s), eps);
+  for (int c = threadIdx.x; c < C; c += 256) st<T>(y + b * C + c, x[b * C + c] * inv);
+}
+
+// ------------------------------------------------------------------------------------------- multi-head self-attention
+// qkv [B][T][3*H] (q | k | v, head h at h*HD inside each, nn.MultiheadAttention's in_proj order) -> out [B][T][H].
+// grid (ceil(T/64), heads, B), 4 waves x 16 queries.  Keys stream through LDS in blocks of 64: K row-major [key][HDP] and V
+// transposed [d][key].  Per wave and 32 keys: S^T = K Q^T (rows = keys, cols = queries) -> online softmax per column (= per lane,
+// max across the 4 lane groups by two xor-shuffles) -> P^T stays in the accumulator registers and is the B operand of
+// O^T += V^T P^T (from_acc: contraction slot j of lane group g <-> key 4g+j of the first 16 keys, 16+4g+(j-4) of the second;
+// the V^T fragment is read with the same permutation, two 8-byte LDS reads).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, T* __restrict__ out, int T_, int H, float scale_log2e) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int HDP = HD < 32 ? 32 : HD;                 // contraction width of S (zero-padded for HD 16)
+  constexpr int KS = HDP / 32;                           // k-steps of S
+  constexpr int DT = HD / 16;                            // 16-row tiles of O^T
+  constexpr int KB = 64;                                 // keys per LDS block
+  constexpr int KRS = HDP * 2 + 16;                      // K row stride (bytes)
+  constexpr int VRS = KB * 2 + 8;                        // V^T row stride (bytes)
+  __shared__ __attribute__((aligned(16))) char kl[KB * KRS];
+  __shared__ __attribute__((aligned(16))) char vl[HD * VRS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const long rs = 3L * H;                                // qkv row stride (elements)
+  const T* base = qkv + (long)b * T_ * rs + (long)h * HD;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  // Q^T operand: B[k = d][col = query l15]
+  V qf[KS];
+  {
+    int qi = q0 + l15; if (qi >= T_) qi = T_ - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int d = ks * 32 + g * 8;
+      if (d < HD) qf[ks] = M::load_b(base + (long)qi * rs + d);
+      else { u32x4 z = {0u, 0u, 0u, 0u}; qf[ks].v = __builtin_bit_cast(decltype(qf[ks].v), z); }
+    }
+  }
+  f32x4 acc[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun = -3.0e38f, lrun = 0.f;
+
+  for (int kb = 0; kb < T_; kb += KB) {
+    __syncthreads();
+    // stage K (row-major, zero rows past T, zero pad columns) and V^T
+    constexpr int PCS = HD / 8;                          // 16-byte pieces per key row
+    for (int i = tid; i < KB * PCS; i += 256) {
+      const int key = i / PCS, pc = i % PCS;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (kb + key < T_) {
+        const T* rowp = base + (long)(kb + key) * rs + pc * 8;
+        kv = *reinterpret_cast<const uint4*>(rowp + H);
+        vv = *reinterpret_cast<const uint4*>(rowp + 2 * H);
+      }
+      *reinterpret_cast<uint4*>(kl + key * KRS + pc * 16) = kv;
+      if (HD < HDP && pc == 0) {
+#pragma unroll
+        for (int z = HD / 8; z < HDP / 8; ++z) *reinterpret_cast<uint4*>(kl + key * KRS + z * 16) = make_uint4(0, 0, 0, 0);
+      }
+      const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(vl + (pc * 8 + e) * VRS + key * 2) = ve[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sb = 0; sb < KB; sb += 32) {
+      if (kb + sb >= T_) break;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const V ka = M::load_b(kl + (sb + l15) * KRS + (ks * 32 + g * 8) * 2);
+        const V kb2 = M::load_b(kl + (sb + 16 + l15) * KRS + (ks * 32 + g * 8) * 2);
+        s0 = M::mma(ka, qf[ks], s0);
+        s1 = M::mma(kb2, qf[ks], s1);
+      }
+      // lane: query l15, keys kb+sb+4g+r (s0) and kb+sb+16+4g+r (s1)
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = (kb + sb + 4 * g + r < T_) ? s0[r] * scale_log2e : -3.0e38f;
+        s1[r] = (kb + sb + 16 + 4 * g + r < T_) ? s1[r] * scale_log2e : -3.0e38f;
+        mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun, mx);
+      const float corr = exp2f(mrun - mnew);
+      mrun = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = exp2f(s0[r] - mnew); s1[r] = exp2f(s1[r] - mnew);
+        ps += s0[r] + s1[r];
+      }
+      lrun = lrun * corr + ps;
+      const V pf = M::from_acc(s0, s1);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const char* vp = vl + (dt * 16 + l15) * VRS + (sb + 4 * g) * 2;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vp), hi = *reinterpret_cast<const u32x2*>(vp + 32);
+        u32x4 u = {lo[0], lo[1], hi[0], hi[1]};
+        V va; va.v = __builtin_bit_cast(decltype(va.v), u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[dt][r] *= corr;
+        acc[dt] = M::mma(va, pf, acc[dt]);
+      }
+    }
+  }
+  float l = lrun;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  const int qi = q0 + l15;
+  if (qi < T_) {
+    T* op = out + ((long)b * T_ + qi) * H + (long)h * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      float o[4] = {acc[dt][0] * inv, acc[dt][1] * inv, acc[dt][2] * inv, acc[dt][3] * inv};
+      M::store4(op + dt * 16 + 4 * g, o);
+    }
+  }
+}
+
+// fp32-storage (parity-grade) and odd head sizes: one thread per (b, h, query), two passes over the keys.
+template <typename T>
+__global__ __launch_bounds__(64) void mha_naive_kernel(const T* __restrict__ qkv, T* __restrict__ out, int T_, int H, int HD, float scale) {
+  const int qi = blockIdx.x * 64 + threadIdx.x, h = blockIdx.y, b = blockIdx.z;
+  if (qi >= T_) return;
+  const long rs = 3L * H;
+  const T* base = qkv + (long)b * T_ * rs + (long)h * HD;
+  const T* qp = base + (long)qi * rs;
+  float m = -3.0e38f;
+  for (int k = 0; k < T_; ++k) {
+    float s = 0.f;
+    for (int d = 0; d < HD; ++d) s += ld<T>(qp + d) * ld<T>(base + (long)k * rs + H + d);
+    m = fmaxf(m, s * scale);
+  }
+  float l = 0.f;
+  float o[128];
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int k = 0; k < T_; ++k) {
+    float s = 0.f;
+    for (int d = 0; d < HD; ++d) s += ld<T>(qp + d) * ld<T>(base + (long)k * rs + H + d);
+    const float p = __expf(s * scale - m);
+    l += p;
+    for (int d = 0; d < HD; ++d) o[d] += p * ld<T>(base + (long)k * rs + 2 * H + d);
+  }
+  T* op = out + ((long)b * T_ + qi) * H + (long)h * HD;
+  for (int d = 0; d < HD; ++d) st<T>(op + d, o[d] / l);
+}
+
+}  // namespace mv
+
+using namespace mv;
+
+static inline unsigned grid_for(long n, int per_block, unsigned cap = 65535u * 16u) {
+  long g = (n + per_block - 1) / per_block;
+  return (unsigned)(g < 1 ? 1 : (g > (long)cap ? cap : g));
+}
+
+extern "C" int mv_add_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* y, long rows, int C, float eps,
+                                int dtype, void* stream) {
+  MV_CHECK_ARG(x && gamma && beta && y && rows > 0 && C > 0 && C % 8 == 0 && C <= 4096);
+  MV_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+#define MV_LN(NV_) MV_DISPATCH(dtype, hipLaunchKernelGGL((add_layernorm_kernel<T, NV_>), grid, dim3(256), 0, (hipStream_t)stream, \
+                               (const T*)x, (const T*)res, gamma, beta, (T*)y, rows, C, eps))
+  if (C <= 512) { MV_LN(1); } else if (C <= 1024) { MV_LN(2); } else if (C <= 2048) { MV_LN(4); } else { MV_LN(8); }
+#undef MV_LN
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mean_t_cl(const void* x, float* out, int B, int T_, int C, int dtype, void* stream) {
+  MV_CHECK_ARG(x && out && B > 0 && T_ > 0 && C > 0 && B <= 65535);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(mean_t_kernel<T>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const T*)x, out, T_, C,
+                                        1.f / (float)T_));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, float* gate, int B, int C,
+                          int R, void* stream) {
+  MV_CHECK_ARG(mean && w1 && b1 && w2 && b2 && gate && B > 0 && C > 0 && R > 0 && (size_t)(C + R) * 4 <= 64 * 1024);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + R) * 4, (hipStream_t)stream, mean, w1, b1, w2, b2, gate, C, R);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_scale_add_cl(const void* x, const float* gate, const void* res, void* y, int B, int T_, int C, int dtype, void* stream) {
+  MV_CHECK_ARG(x && gate && res && y && B > 0 && T_ > 0 && C > 0 && C % 8 == 0);
+  MV_CHECK_ARG((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0);
+  const long n8 = (long)B * T_ * (C / 8);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(scale_add_kernel<T>, dim3(grid_for(n8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)x, gate,
+                                        (const T*)res, (T*)y, n8, T_, C));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_res2_glue(const void* src, int src_stride, const void* u, void* cat, void* nxt, long rows, int C, int cs, int dst_off,
+                            int nxt_off, int dtype, void* stream) {
+  MV_CHECK_ARG(src && cat && rows > 0 && C > 0 && cs > 0 && cs % 8 == 0 && C % 8 == 0 && src_stride % 8 == 0 && dst_off % 8 == 0);
+  MV_CHECK_ARG(dst_off >= 0 && dst_off + cs <= C && (!nxt || (u && nxt_off % 8 == 0 && nxt_off >= 0 && nxt_off + cs <= C)));
+  MV_CHECK_ARG((((uintptr_t)src | (uintptr_t)u | (uintptr_t)cat | (uintptr_t)nxt) & 15) == 0);
+  const long n = rows * (cs / 8);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(res2_glue_kernel<T>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const T*)src,
+                                        src_stride, (const T*)u, (T*)cat, (T*)nxt, rows, C, cs, dst_off, nxt_off));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" size_t mv_asp_workspace_bytes(int B, int T_) { return (size_t)B * T_ * sizeof(float2); }
+
+extern "C" int mv_asp_pool(const void* x, const void* logits, void* workspace, float* pooled, int B, int T_, int C, int dtype, void* stream) {
+  MV_CHECK_ARG(x && logits && workspace && pooled && B > 0 && T_ > 1 && C > 0 && C % 8 == 0 && B <= 65535);
+  MV_CHECK_ARG((((uintptr_t)x | (uintptr_t)logits | (uintptr_t)workspace) & 15) == 0);
+  const long rows = (long)B * T_;
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(asp_rowstat_kernel<T>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                                        (const T*)logits, (float2*)workspace, rows, C));
+  MV_LAUNCH_CHECK();
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(asp_pool_kernel<T>, dim3(cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                        (const T*)logits, (const float2*)workspace, pooled, T_, C));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_l2norm_rows(const float* x, void* y, int B, int C, float eps, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && B > 0 && C > 0);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(l2norm_rows_kernel<T>, dim3(B), dim3(256), 0, (hipStream_t)stream, x, (T*)y, C, eps));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mha_fwd(const void* qkv, void* out, int B, int T_, int nheads, int head_dim, int dtype, void* stream) {
+  MV_CHECK_ARG(qkv && out && B > 0 && T_ > 0 && nheads > 0 && head_dim > 0 && head_dim <= 128 && B <= 65535 && nheads <= 65535);
+  const int H = nheads * head_dim;
+  const float scale = 1.f / sqrtf((float)head_dim);
+  hipStream_t st_ = (hipStream_t)stream;
+  const bool mfma_ok = dtype != MV_F32 && (head_dim == 16 || head_dim == 32 || head_dim == 64) &&
+                       (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0;
+  if (mfma_ok) {
+    const dim3 grid(cdiv(T_, 64), nheads, B);
+    const float sl2 = scale * 1.44269504088896f;
+#define MV_MHA(TT, HD_) hipLaunchKernelGGL((mha_kernel<TT, HD_>), grid, dim3(256), 0, st_, (const TT*)qkv, (TT*)out, T_, H, sl2)
+#define MV_MHA_T(TT) do { if (head_dim == 64) MV_MHA(TT, 64); else if (head_dim == 32) MV_MHA(TT, 32); else MV_MHA(TT, 16); } while (0)
+    if (dtype == MV_BF16) MV_MHA_T(bf16); else if (dtype == MV_F16) MV_MHA_T(f16); else return MV_ERR_DTYPE;
+#undef MV_MHA_T
+#undef MV_MHA
+  } else {
+    const dim3 grid(cdiv(T_, 64), nheads, B);
+    MV_DISPATCH(dtype, hipLaunchKernelGGL(mha_naive_kernel<T>, grid, dim3(64), 0, st_, (const T*)qkv, (T*)out, T_, H, head_dim, scale));
+  }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}

@@ -14,6 +14,7 @@ from .discriminators import (HiFiGANDiscriminators, MultiPeriodDiscriminator, Mu
 from .streaming import ChunkedVocoder
 from .data import MelFrontEnd, ClipSampler
 from .plain_hifigan import PlainHiFiGANGenerator
+from .embedding_extractors import ECAPA_TDNN, SE_Res2Block, SE_Module, Emotion2Vec, EmbeddingExtractor
 
 __all__ = [
     "ODConv1d", "ODConvTranspose1d", "GRC_LoRA_Block", "FiLMLayer", "MultiReceptiveFieldBlock",
@@ -21,4 +22,5 @@ __all__ = [
     "HiFiGANDiscriminators", "MultiPeriodDiscriminator", "MultiScaleDiscriminator", "Discriminator1D",
     "Discriminator2D", "ModifiedHiFiGANVocoder", "VocoderTrainer", "ConditionedHiFiGAN", "HiFiGANTrainer",
     "ChunkedVocoder", "MelFrontEnd", "ClipSampler", "PlainHiFiGANGenerator",
+    "ECAPA_TDNN", "SE_Res2Block", "SE_Module", "Emotion2Vec", "EmbeddingExtractor",
 ]

@@ -5,8 +5,8 @@ discriminators, LSGAN + output-L1 "feature matching" + mel-L1 losses, weights 10
 (:186-248: G forward once -> D step on the detached fake -> G step with the discriminators re-evaluated).
 
 Differences, all documented in DESIGN.md: the generator is the one ``conditioned_hifigan`` is written against (SURVEY.md
-§A; the reference's current-source generator does not construct); the embedding extractor (``embedding_extractors.py``,
-out of scope and broken upstream) is not built - pass embeddings explicitly; the mel term is a real log-mel/STFT L1
+§A; the reference's current-source generator does not construct); the embedding extractor (``embedding_extractors.py``)
+runs frozen (eval statistics, no gradient) with its one broken layer resized, see that module; the mel term is a real log-mel/STFT L1
 (``mel_mode="stft"``) instead of the reference's ``generated_mel = mel`` placeholder (``mel_mode="placeholder"``
 reproduces that: the term is then identically zero).
 """
@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import functional as Fn
 from .discriminators import HiFiGANDiscriminators
+from .embedding_extractors import EmbeddingExtractor
 from .generator import ModifiedHiFiGANGenerator
 from .mel import mel_filterbank
 
@@ -32,7 +33,8 @@ class ModifiedHiFiGANVocoder(nn.Module):
                                                   speaker_embedding_dim=speaker_embedding_dim,
                                                   emotion_embedding_dim=emotion_embedding_dim, **generator_kwargs)
         self.discriminators = HiFiGANDiscriminators()
-        self.embedding_extractor = None     # conditioning producer: out of scope
+        self.embedding_extractor = EmbeddingExtractor(speaker_embedding_dim=speaker_embedding_dim,
+                                                      emotion_embedding_dim=emotion_embedding_dim)     # complete_vocoder.py:39-42
         self.fm_weight = 10.0
         self.mel_weight = 45.0
         hop_total = 1
@@ -43,6 +45,10 @@ class ModifiedHiFiGANVocoder(nn.Module):
 
     def forward(self, mel_spectrogram, speaker_embedding=None, emotion_embedding=None,
                 extract_embeddings: bool = True) -> Dict[str, torch.Tensor]:
+        if extract_embeddings and (speaker_embedding is None or emotion_embedding is None):     # complete_vocoder.py:65-69
+            spk, emo = self.embedding_extractor(mel_spectrogram)
+            speaker_embedding = spk if speaker_embedding is None else speaker_embedding
+            emotion_embedding = emo if emotion_embedding is None else emotion_embedding
         wave = self.generator(mel_spectrogram, speaker_embedding, emotion_embedding)
         return {"generated_waveform": wave, "speaker_embedding": speaker_embedding, "emotion_embedding": emotion_embedding}
 

@@ -223,6 +223,8 @@ def linear(x, w, b=None):
     x = _c(x)
     M, Kd = x.shape
     Nn = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != Kd or (b is not None and b.numel() != Nn) or w.dtype != x.dtype:
+        raise RuntimeError(f"linear: x {tuple(x.shape)} {x.dtype} cannot be multiplied with weight {tuple(w.shape)} {w.dtype}")
     y = torch.empty(M, Nn, device=x.device, dtype=x.dtype)
     N.call("mv_linear_fwd", _p(x), _p(_c(w)), _p(_c(b)), _p(y), M, Nn, Kd, _dt(x), _stream())
     return y

@@ -352,6 +352,34 @@ int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* s
 int mv_take_channel(const void* x, void* out, long rows, int C, int c, int dtype, void* stream);
 int mv_put_channel(const void* g, void* y, long rows, int C, int c, int dtype, void* stream);
 
+/* ---- Conditioning producers (reference embedding_extractors.py).  Channels-last [B][T][C] activations;
+ * the Conv1d / Linear layers run on mv_dconv_cl_fwd with BatchNorm folded into the packed weights. ---- */
+/* y = LayerNorm(x + res) * gamma + beta over the last axis (nn.TransformerEncoderLayer post-norm, embedding_extractors.py:195-203);
+ * res may be NULL; C % 8 == 0, C <= 4096. */
+int mv_add_layernorm(const void* x, const void* res, const float* gamma, const float* beta, void* y, long rows, int C, float eps,
+                     int dtype, void* stream);
+/* out fp32 [B][C] = mean over T of x [B][T][C] (SE squeeze :166, utterance mean pooling :241). */
+int mv_mean_t_cl(const void* x, float* out, int B, int T, int C, int dtype, void* stream);
+/* gate[b][c] = sigmoid(W2 relu(W1 mean_b + b1) + b2): SE_Module.fc (embedding_extractors.py:159-164), fp32 masters W1 [R][C], W2 [C][R]. */
+int mv_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, float* gate, int B, int C,
+               int R, void* stream);
+/* y = x * gate[b][c] + res (SE scale :169 + block residual :149). */
+int mv_scale_add_cl(const void* x, const float* gate, const void* res, void* y, int B, int T, int C, int dtype, void* stream);
+/* Res2Net chain step (embedding_extractors.py:135-143): cat[row][dst_off..+cs) = src[row][0..cs) (src rows `src_stride` elements apart);
+ * when nxt != NULL also nxt[row][0..cs) = u[row][nxt_off..+cs) + src[row][0..cs).  u, cat: [rows][C]; nxt: [rows][cs]. */
+int mv_res2_glue(const void* src, int src_stride, const void* u, void* cat, void* nxt, long rows, int C, int cs, int dst_off,
+                 int nxt_off, int dtype, void* stream);
+/* Attentive statistics pooling (embedding_extractors.py:73-84): w = softmax over the C channels of logits[b][t][:], a = x * w,
+ * pooled[b][0..C) = mean_t a, pooled[b][C..2C) = unbiased std_t a.  workspace: mv_asp_workspace_bytes(B, T). */
+size_t mv_asp_workspace_bytes(int B, int T);
+int mv_asp_pool(const void* x, const void* logits, void* workspace, float* pooled, int B, int T, int C, int dtype, void* stream);
+/* y[b][:] = x[b][:] / max(||x[b]||_2, eps) (F.normalize, embedding_extractors.py:90,245); x fp32, y in `dtype`. */
+int mv_l2norm_rows(const float* x, void* y, int B, int C, float eps, int dtype, void* stream);
+/* Multi-head self-attention of nn.MultiheadAttention (embedding_extractors.py:195-203): qkv [B][T][3*H] = in_proj(x) (q | k | v),
+ * out [B][T][H] = concat_h softmax(q_h k_h^T / sqrt(head_dim)) v_h, before out_proj.  16-bit storage with head_dim 16/32/64: MFMA
+ * flash kernel; otherwise (fp32 parity grade) a scalar kernel. */
+int mv_mha_fwd(const void* qkv, void* out, int B, int T, int nheads, int head_dim, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,165 @@
+"""GPU parity of the conditioning producers: product modules (HIP kernels through the C ABI) against the
+golden vectors generated from the reference's embedding_extractors.py, and the new kernels one by one against fp64 torch math.
+Tolerances (rel-L2): fp32 storage 1e-4 (bf16x3-free generic fp32 kernels), fp16 5e-3, bf16 3e-2 on L2-normalised embeddings."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import load_golden
+from embed_cases import CASES, build
+from oracle.vocoder_oracle import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 1e-4, torch.float16: 5e-3, torch.bfloat16: 3e-2}
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def H():
+    import hifigan_modified as H
+    from hifigan_modified import _native
+    _native.lib()
+    return H
+
+
+def _x(g, dtype):
+    return torch.from_numpy(g["x"]).cuda().to(dtype)
+
+
+def _err(y, g, key, sl=None):
+    y = y.float().cpu()
+    if sl is not None:
+        y = y[sl]
+    return rel_l2(y, torch.from_numpy(g[key]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_se_module_and_res2_block(H, dtype):
+    g = load_golden("embed_se_module_c64")
+    m = build("se", g, channels=64).cuda()
+    assert _err(m(_x(g, dtype)), g, "y") < TOL[dtype]
+    g = load_golden("embed_se_res2_c256_d3")
+    m = build("res2", g, channels=256, dilation=3).cuda()
+    assert _err(m(_x(g, dtype)), g, "y") < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["embed_ecapa_h512_t100", "embed_ecapa_h256_t37"])
+def test_ecapa_vs_reference_golden(H, name, dtype):
+    g = load_golden(name)
+    m = build("ecapa", g, **CASES[name][1]).cuda()
+    x = _x(g, dtype)
+    pooled = m.pooled_cl(x)
+    assert _err(pooled, g, "pooled") < 2 * TOL[dtype]
+    emb, logits = m(x)
+    assert logits is None and emb.dtype == dtype and emb.shape == (2, 192)
+    assert _err(emb, g, "embedding") < TOL[dtype]
+    m.train(True)                                  # frozen producer: same embedding, logits returned for arity
+    emb2, logits = m(x)
+    assert torch.equal(emb, emb2) and logits.shape == (2, 16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("name", ["embed_emotion_h512_t100", "embed_emotion_h128_t37"])
+def test_emotion2vec_vs_reference_golden(H, name, dtype):
+    g = load_golden(name)
+    m = build("emotion", g, **CASES[name][1]).cuda()
+    frame, utt, logits = m(_x(g, dtype))
+    assert logits is None and frame.shape == tuple(g["frame"].shape) and utt.shape == (2, 256)
+    assert _err(frame, g, "frame") < 2 * TOL[dtype]
+    assert _err(utt, g, "utterance") < 2 * TOL[dtype]
+    # training mode: the reference feeds the [B, embedding_dim] utterance embedding to Linear(hidden_dim, .) (:250 vs :209) and
+    # raises a shape error unless the two sizes agree; same behaviour here (never an out-of-bounds read)
+    m.train(True)
+    with pytest.raises(RuntimeError):
+        m(_x(g, dtype))
+    m2 = build("emotion", None, hidden_dim=256, embedding_dim=256).cuda().train(True)
+    fr, ut, logits = m2(_x(g, dtype))
+    assert logits.shape == (2, 8) and torch.isfinite(logits.float()).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_combined_extractor_and_vocoder_hook(H, dtype):
+    g = load_golden("embed_extractor_t32")
+    m = build("extractor", g).cuda()
+    spk, emo = m(_x(g, dtype))
+    assert _err(spk, g, "speaker") < TOL[dtype] and _err(emo, g, "emotion") < 2 * TOL[dtype]
+    # ModifiedHiFiGANVocoder.forward(extract_embeddings=True) (complete_vocoder.py:65-69) conditions on the extracted embeddings
+    torch.manual_seed(0)
+    voc = H.ModifiedHiFiGANVocoder().cuda().train(False)
+    voc.embedding_extractor.load_state_dict(m.state_dict())
+    x = _x(g, dtype)
+    with torch.no_grad():
+        out = voc(x)
+        assert torch.equal(out["speaker_embedding"], spk) and torch.equal(out["emotion_embedding"], emo)
+        ref = voc(x, spk, emo, extract_embeddings=False)["generated_waveform"]
+        assert torch.equal(out["generated_waveform"], ref) and ref.shape == (2, 1, 32 * 256)
+        plain = voc(x, extract_embeddings=False)
+        assert plain["speaker_embedding"] is None and not torch.equal(plain["generated_waveform"], ref)
+        only_spk = voc(x, speaker_embedding=spk.flip(0))
+        assert torch.equal(only_spk["speaker_embedding"], spk.flip(0)) and torch.equal(only_spk["emotion_embedding"], emo)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,T,nh,hd", [(2, 1, 8, 64), (2, 37, 8, 64), (3, 64, 8, 64), (2, 100, 8, 16), (1, 345, 4, 32), (2, 130, 2, 64)])
+def test_mha_kernel_vs_fp64(H, dtype, B, T, nh, hd):
+    from hifigan_modified import _native as N_, ops
+    torch.manual_seed(B * 1000 + T)
+    Hd = nh * hd
+    qkv = (torch.randn(B, T, 3 * Hd, device="cuda") * 1.5).to(dtype)
+    out = torch.empty(B, T, Hd, device="cuda", dtype=dtype)
+    N_.call("mv_mha_fwd", ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(out.data_ptr()), B, T, nh, hd, ops._dt(qkv), ops._stream())
+    q, k, v = (t.double().view(B, T, nh, hd).transpose(1, 2) for t in qkv.split(Hd, dim=-1))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / hd ** 0.5, dim=-1) @ v).transpose(1, 2).reshape(B, T, Hd)
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.2e-2}[dtype]
+    assert rel_l2(out.double().cpu(), ref.cpu()) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(7, 512), (200, 128), (5, 2048), (3, 1536)])
+def test_add_layernorm_vs_fp64(H, dtype, rows, C):
+    from hifigan_modified import _native as N_, ops
+    torch.manual_seed(rows)
+    x, r = torch.randn(rows, C, device="cuda").to(dtype), torch.randn(rows, C, device="cuda").to(dtype)
+    gam, bet = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1
+    y = torch.empty_like(x)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N_.call("mv_add_layernorm", P(x), P(r), P(gam), P(bet), P(y), rows, C, 1e-5, ops._dt(x), ops._stream())
+    ref = torch.nn.functional.layer_norm(x.double() + r.double(), (C,), gam.double(), bet.double(), 1e-5)
+    assert rel_l2(y.double().cpu(), ref.cpu()) < {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 6e-3}[dtype]
+    N_.call("mv_add_layernorm", P(x), None, P(gam), P(bet), P(y), rows, C, 1e-5, ops._dt(x), ops._stream())
+    ref = torch.nn.functional.layer_norm(x.double(), (C,), gam.double(), bet.double(), 1e-5)
+    assert rel_l2(y.double().cpu(), ref.cpu()) < {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 6e-3}[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,C", [(2, 96, 1536), (3, 33, 768), (1, 2, 64)])
+def test_attentive_statistics_pooling_vs_fp64(H, dtype, B, T, C):
+    from hifigan_modified import _native as N_, ops
+    torch.manual_seed(T)
+    x, lg = torch.randn(B, T, C, device="cuda").to(dtype), (torch.randn(B, T, C, device="cuda") * 2).to(dtype)
+    ws = torch.empty(N_.lib().mv_asp_workspace_bytes(B, T), device="cuda", dtype=torch.uint8)
+    pooled = torch.empty(B, 2 * C, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N_.call("mv_asp_pool", P(x), P(lg), P(ws), P(pooled), B, T, C, ops._dt(x), ops._stream())
+    a = x.double() * torch.softmax(lg.double(), dim=2)
+    ref = torch.cat([a.mean(dim=1), a.std(dim=1)], dim=1)
+    assert rel_l2(pooled.double().cpu(), ref.cpu()) < 2e-5
+
+
+def test_extractor_rejects_bad_input_and_follows_weight_updates(H):
+    m = build("ecapa", None, hidden_dim=256, num_speakers=4).cuda()
+    with pytest.raises(RuntimeError):
+        m(torch.randn(2, 80, 5, device="cuda"))            # valid k=5 conv + unbiased std need >= 6 frames
+    with pytest.raises(RuntimeError):
+        m(torch.randn(2, 80, 50))                           # CPU tensor: no fallback
+    x = torch.randn(2, 80, 50, device="cuda").half()
+    e0 = m(x)[0]
+    with torch.no_grad():
+        m.bn1.running_mean.add_(0.5)                        # buffers are part of the folded weights: cache must notice
+    e1 = m(x)[0]
+    assert not torch.equal(e0, e1)
+    with torch.no_grad():
+        m.bn1.running_mean.sub_(0.5)
+    assert rel_l2(m(x)[0].float().cpu(), e0.float().cpu()) < 1e-3
