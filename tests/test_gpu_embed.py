@@ -94,9 +94,12 @@ def test_combined_extractor_and_vocoder_hook(H, dtype):
         out = voc(x)
         assert torch.equal(out["speaker_embedding"], spk) and torch.equal(out["emotion_embedding"], emo)
         ref = voc(x, spk, emo, extract_embeddings=False)["generated_waveform"]
-        assert torch.equal(out["generated_waveform"], ref) and ref.shape == (2, 1, 32 * 256)
+        # same inputs, two runs: the generator's fp32 atomics (pooling sums) make runs agree to rounding, not bit for bit
+        rt = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1e-2}[dtype]
+        assert rel_l2(out["generated_waveform"].float().cpu(), ref.float().cpu()) < rt and ref.shape == (2, 1, 32 * 256)
         plain = voc(x, extract_embeddings=False)
-        assert plain["speaker_embedding"] is None and not torch.equal(plain["generated_waveform"], ref)
+        assert plain["speaker_embedding"] is None
+        assert rel_l2(plain["generated_waveform"].float().cpu(), ref.float().cpu()) > 10 * rt      # FiLM skipped without embeddings
         only_spk = voc(x, speaker_embedding=spk.flip(0))
         assert torch.equal(only_spk["speaker_embedding"], spk.flip(0)) and torch.equal(only_spk["emotion_embedding"], emo)
 
