@@ -1071,7 +1071,10 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
     p.cchunk = nb8 ? 64 : (Cin > 128 ? 128 : Cin);
     if (use && Cin % p.cchunk == 0 && (p.cchunk == 128 || p.cchunk == 64 || p.cchunk == 32)) {
       const size_t xb = (size_t)kh * (npos + (kw - 1) * dil_w) * lds_row_stride(p.cchunk * 2, 2);
-      const int rows = (big3x3 || (nb8 && Cout >= 256)) ? 256 : Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
+      int rows = (big3x3 || (nb8 && Cout >= 256)) ? 256 : Cout >= 128 ? 128 : (Cout >= 64 ? 64 : 32);
+      // short sequences (the conditioning producers: a few hundred positions in all): narrower row tiles until the grid covers the chip
+      if (!nb8 && !big3x3)
+        while (rows > 32 && (long)cdiv(W, npos) * cdiv(Cout, rows) * B * H < 256) rows >>= 1;
       const size_t ob = (size_t)npos * (rows * 2 + 16);
       const size_t ldsb = xb > ob ? xb : ob;
       if (ldsb <= 160 * 1024) {

@@ -96,24 +96,29 @@ __global__ __launch_bounds__(256) void mean_t_kernel(const T* __restrict__ x, fl
 
 // ------------------------------------------------------------------------------------------- SE excitation
 // gate[b][c] = sigmoid(W2[c][:] . relu(W1 m_b + b1) + b2[c]);  W1 [R][C], W2 [C][R] fp32 masters; one block per sample.
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate,
-                                                      int C, int R) {
+__global__ __launch_bounds__(1024) void se_gate_kernel(const float* __restrict__ m, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ gate,
+                                                       int C, int R) {
   extern __shared__ float sm[];                          // m_b [C] | h [R]
   float* ml = sm; float* hl = sm + C;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < C; c += 256) ml[c] = m[(long)b * C + c];
+  for (int c = threadIdx.x; c < C; c += 1024) ml[c] = m[(long)b * C + c];
   __syncthreads();
-  for (int r = wid; r < R; r += 4) {                     // one wave per hidden unit
+  for (int r = wid; r < R; r += 16) {                    // one wave per hidden unit, 16 units in flight
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += w1[(long)r * C + c] * ml[c];
     s = wave_sum(s);
     if (lane == 0) hl[r] = fmaxf(s + b1[r], 0.f);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += 1024) {
     float s = b2[c];
-    for (int r = 0; r < R; ++r) s += w2[(long)c * R + r] * hl[r];
+    const float* wr = w2 + (long)c * R;
+    if ((R & 3) == 0) {
+      for (int r = 0; r < R; r += 4) { const float4 w = *reinterpret_cast<const float4*>(wr + r); s += w.x * hl[r] + w.y * hl[r + 1] + w.z * hl[r + 2] + w.w * hl[r + 3]; }
+    } else {
+      for (int r = 0; r < R; ++r) s += wr[r] * hl[r];
+    }
     gate[(long)b * C + c] = 1.f / (1.f + __expf(-s));
   }
 }
@@ -408,7 +413,7 @@ extern "C" int mv_mean_t_cl(const void* x, float* out, int B, int T_, int C, int
 extern "C" int mv_se_gate(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, float* gate, int B, int C,
                           int R, void* stream) {
   MV_CHECK_ARG(mean && w1 && b1 && w2 && b2 && gate && B > 0 && C > 0 && R > 0 && (size_t)(C + R) * 4 <= 64 * 1024);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), (size_t)(C + R) * 4, (hipStream_t)stream, mean, w1, b1, w2, b2, gate, C, R);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(1024), (size_t)(C + R) * 4, (hipStream_t)stream, mean, w1, b1, w2, b2, gate, C, R);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

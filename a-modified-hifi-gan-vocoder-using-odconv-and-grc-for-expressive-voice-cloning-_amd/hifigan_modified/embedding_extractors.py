@@ -68,6 +68,9 @@ class _Affine:
     def __call__(self, x_cl: torch.Tensor, act=_NONE) -> torch.Tensor:
         kind, slope = act
         if self.mfma and x_cl.shape[-1] == self.cinp:
+            if self.ks == 1:        # rows are independent: one long sequence fills the 128-position tiles whatever T is
+                B, T, C = x_cl.shape
+                return ops.dconv_cl(x_cl.view(1, B * T, C), self.packed, self.bias, self.cout, 1, 1, 1, kind, slope).view(B, T, self.cout)
             return ops.dconv_cl(x_cl, self.packed, self.bias, self.cout, 1, self.ks, self.dil, kind, slope)
         if self.mfma:
             raise RuntimeError(f"channels-last input has {x_cl.shape[-1]} channels, packed weights expect {self.cinp}")

@@ -41,3 +41,32 @@ class GraphedVocoder:
         if self.emo is not None:
             self.emo.copy_(emotion_emb)
         return self.replay()
+
+
+class GraphedExtractor:
+    """One captured forward of the conditioning producers (`EmbeddingExtractor`, ~110 short launches): replayed on a static mel
+    buffer, returns the static (speaker, emotion) embedding tensors."""
+
+    def __init__(self, extractor, mel, warmup=2):
+        if not mel.is_cuda:
+            raise RuntimeError("GraphedExtractor needs GPU tensors: this path has no CPU fallback")
+        self.extractor = extractor
+        self.mel = mel.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                extractor(self.mel)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = extractor(self.mel)
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, mel):
+        self.mel.copy_(mel)
+        return self.replay()
