@@ -380,6 +380,67 @@ __global__ __launch_bounds__(64) void mha_naive_kernel(const T* __restrict__ qkv
   for (int d = 0; d < HD; ++d) st<T>(op + d, o[d] / l);
 }
 
+
+// ------------------------------------------------------------------------------------------- skinny 1x1 GEMM (few positions)
+// y[M][N] = act(x[M][K] W^T + bias) for the conditioning producers' short sequences (M = B*T ~ 1e3 rows): the tiled conv kernels
+// of disc_fused.hip are latency-bound there (one LDS round trip per 128-channel chunk, <= 1 workgroup per CU).  Here a workgroup
+// owns 32 positions x 64 output channels and its 8 waves SPLIT K: wave w takes k-steps [w*PER, (w+1)*PER), issues ALL its operand
+// loads up front (weights from the packed A-fragment image of mv_dconv_pack, activations straight from global as B operands - no
+// LDS staging, no barrier before the MFMAs), so a launch costs about one memory latency.  Partial tiles are summed through LDS,
+// wave f finishing fragment f (bias + activation + 8-byte channels-last stores).
+template <typename T, int PER, typename ActF>
+__global__ __launch_bounds__(512) void gemm_skinny_kernel(const T* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
+                                                          T* __restrict__ y, int Mrows, int K, int Nc, ActF actf) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int MT = 4, NP = 2;
+  __shared__ __attribute__((aligned(16))) float red[8][MT * NP][64][4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
+  const int p0 = blockIdx.x * (16 * NP), mt0 = blockIdx.y * MT;
+  const int ksteps = K / 32;
+  V a[PER][MT], b[PER][NP];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ks = wid * PER + i;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a[i][m] = M::load_b(wp + (((long)(mt0 + m) * ksteps + ks) * 64 + lane) * 8);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      int pos = p0 + 16 * n + l15; if (pos >= Mrows) pos = Mrows - 1;
+      b[i][n] = M::load_b(x + (long)pos * K + ks * 32 + g * 8);
+    }
+  }
+  f32x4 acc[MT][NP];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NP; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NP; ++n) acc[m][n] = M::mma(a[i][m], b[i][n], acc[m][n]);
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NP; ++n) *reinterpret_cast<f32x4*>(&red[wid][m * NP + n][lane][0]) = acc[m][n];
+  __syncthreads();
+  f32x4 sum = *reinterpret_cast<const f32x4*>(&red[0][wid][lane][0]);
+#pragma unroll
+  for (int w = 1; w < 8; ++w) { const f32x4 t = *reinterpret_cast<const f32x4*>(&red[w][wid][lane][0]); sum += t; }
+  const int m = wid / NP, n = wid % NP;
+  const int pos = p0 + 16 * n + l15, co = (mt0 + m) * 16 + 4 * g;
+  if (pos < Mrows) {
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) M::load4(bias + co, bv);
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = actf(sum[r] + bv[r]);
+    M::store4(y + (long)pos * Nc + co, o);
+  }
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -481,6 +542,42 @@ extern "C" int mv_mha_fwd(const void* qkv, void* out, int B, int T_, int nheads,
     const dim3 grid(cdiv(T_, 64), nheads, B);
     MV_DISPATCH(dtype, hipLaunchKernelGGL(mha_naive_kernel<T>, grid, dim3(64), 0, st_, (const T*)qkv, (T*)out, T_, H, head_dim, scale));
   }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+template <typename T, typename ActF>
+static int skinny_launch(const void* x, const void* wp, const void* bias, void* y, int M, int K, int N, ActF actf, hipStream_t st_) {
+  const dim3 grid(cdiv(M, 32), N / 64);
+#define MV_SK(PER_) hipLaunchKernelGGL((gemm_skinny_kernel<T, PER_, ActF>), grid, dim3(512), 0, st_, (const T*)x, (const T*)wp, (const T*)bias, (T*)y, M, K, N, actf)
+  switch (K / 256) {
+    case 1: MV_SK(1); break;
+    case 2: MV_SK(2); break;
+    case 3: MV_SK(3); break;
+    case 4: MV_SK(4); break;
+    case 6: MV_SK(6); break;
+    case 8: MV_SK(8); break;
+    default: return MV_ERR_UNSUPPORTED;
+  }
+#undef MV_SK
+  return MV_OK;
+}
+
+extern "C" int mv_gemm_cl_skinny(const void* x, const void* packed, const void* bias, void* y, int M, int K, int N, int act, float slope,
+                                 int dtype, void* stream) {
+  MV_CHECK_ARG(x && packed && y && M > 0 && K > 0 && N > 0);
+  MV_CHECK_ARG((((uintptr_t)x | (uintptr_t)packed | (uintptr_t)y | (uintptr_t)bias) & 15) == 0);
+  if (dtype == MV_F32 || K % 256 != 0 || N % 64 != 0 || N / 64 > 65535) return MV_ERR_UNSUPPORTED;
+  hipStream_t st_ = (hipStream_t)stream;
+  int rc;
+  if (act == ACT_TANH || act == ACT_SILU) {
+    const ActAny f{act, slope};
+    rc = dtype == MV_BF16 ? skinny_launch<bf16>(x, packed, bias, y, M, K, N, f, st_) : skinny_launch<f16>(x, packed, bias, y, M, K, N, f, st_);
+  } else {
+    const ActLrelu f{act == ACT_NONE ? 1.f : slope};
+    rc = dtype == MV_BF16 ? skinny_launch<bf16>(x, packed, bias, y, M, K, N, f, st_) : skinny_launch<f16>(x, packed, bias, y, M, K, N, f, st_);
+  }
+  if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -30,6 +30,7 @@ from . import ops
 _RELU = (N.ACT_LRELU, 0.0)
 _NONE = (N.ACT_NONE, 0.0)
 _TANH = (N.ACT_TANH, 0.0)
+_SKINNY_ROWS = 4096     # up to this many positions the split-K GEMM beats the tiled conv kernel (tools/bench_embed.py)
 
 
 def _sig(mod: nn.Module):
@@ -70,6 +71,14 @@ class _Affine:
         if self.mfma and x_cl.shape[-1] == self.cinp:
             if self.ks == 1:        # rows are independent: one long sequence fills the 128-position tiles whatever T is
                 B, T, C = x_cl.shape
+                if B * T <= _SKINNY_ROWS and self.cout % 64 == 0:
+                    y = torch.empty(B, T, self.cout, device=x_cl.device, dtype=x_cl.dtype)
+                    rc = N.lib().mv_gemm_cl_skinny(ops._p(x_cl), ops._p(self.packed), ops._p(self.bias), ops._p(y), B * T, C, self.cout,
+                                                   kind, float(slope), ops._dt(x_cl), ops._stream())
+                    if rc == 0:
+                        return y
+                    if rc != -3:
+                        N.check(rc, "mv_gemm_cl_skinny")
                 return ops.dconv_cl(x_cl.view(1, B * T, C), self.packed, self.bias, self.cout, 1, 1, 1, kind, slope).view(B, T, self.cout)
             return ops.dconv_cl(x_cl, self.packed, self.bias, self.cout, 1, self.ks, self.dil, kind, slope)
         if self.mfma:

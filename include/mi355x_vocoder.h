@@ -379,6 +379,11 @@ int mv_l2norm_rows(const float* x, void* y, int B, int C, float eps, int dtype, 
  * out [B][T][H] = concat_h softmax(q_h k_h^T / sqrt(head_dim)) v_h, before out_proj.  16-bit storage with head_dim 16/32/64: MFMA
  * flash kernel; otherwise (fp32 parity grade) a scalar kernel. */
 int mv_mha_fwd(const void* qkv, void* out, int B, int T, int nheads, int head_dim, int dtype, void* stream);
+/* y [M][N] = act(x [M][K] W^T + bias) for short sequences (M of the order of 1e3 rows): split-K over the 8 waves of a workgroup, operands
+ * straight from global memory, `packed` = mv_dconv_pack_pad(w [N][K][1][1], flip 0).  16-bit storage, K % 256 == 0 with K/256 in
+ * {1,2,3,4,6,8}, N % 64 == 0; otherwise MV_ERR_UNSUPPORTED (callers then use mv_dconv_cl_fwd). */
+int mv_gemm_cl_skinny(const void* x, const void* packed, const void* bias, void* y, int M, int K, int N, int act, float slope,
+                      int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -166,3 +166,24 @@ def test_extractor_rejects_bad_input_and_follows_weight_updates(H):
     with torch.no_grad():
         m.bn1.running_mean.sub_(0.5)
     assert rel_l2(m(x)[0].float().cpu(), e0.float().cpu()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,K,N,act", [(1024, 512, 512, "relu"), (1000, 2048, 512, "none"), (37, 512, 2048, "relu"), (64, 1536, 512, "tanh"),
+                                         (200, 256, 768, "none"), (33, 768, 256, "relu"), (96, 1024, 64, "none")])
+def test_skinny_gemm_vs_fp64(H, dtype, M, K, N, act):
+    from hifigan_modified import _native as N_, ops
+    torch.manual_seed(M + K)
+    x = torch.randn(M, K, device="cuda").to(dtype)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5)
+    b = (torch.randn(N, device="cuda") * 0.1).to(dtype)
+    packed = ops.dconv_pack(w.view(N, K, 1, 1), dtype, 0)
+    y = torch.empty(M, N, device="cuda", dtype=dtype)
+    kind = {"relu": N_.ACT_LRELU, "none": N_.ACT_NONE, "tanh": N_.ACT_TANH}[act]
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N_.call("mv_gemm_cl_skinny", P(x), P(packed), P(b), P(y), M, K, N, kind, 0.0, ops._dt(x), ops._stream())
+    ref = x.double() @ w.to(dtype).double().t() + b.double()
+    ref = {"relu": torch.relu, "none": lambda t: t, "tanh": torch.tanh}[act](ref)
+    assert rel_l2(y.double().cpu(), ref.cpu()) < {torch.float16: 1e-3, torch.bfloat16: 6e-3}[dtype]
+    # unsupported shapes are refused, not mis-computed
+    assert N_.lib().mv_gemm_cl_skinny(P(x), P(packed), P(b), P(y), M, K + 32, N, kind, 0.0, ops._dt(x), ops._stream()) == -3
