@@ -441,6 +441,94 @@ __global__ __launch_bounds__(512) void gemm_skinny_kernel(const T* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------- fused Res2Net chain
+// The 7 dependent k=3 dilated convs of SE_Res2Block (embedding_extractors.py:135-143) in ONE launch instead of 7 convs + 8 glue
+// launches: ys[0] = xs[0]; ys[i] = conv_i(xs[i] + ys[i-1]); cat = concat(ys).  A workgroup owns 64 output positions of one sample and
+// recomputes the halo: step i is evaluated on [t0 - (7-i)d, t0 + 64 + (7-i)d), its input xs[i] + ys[i-1] lives in LDS (two
+// ping-pong tiles, channels-last rows), output channels on MFMA rows so a lane owns 4 consecutive channels of one position
+// (8-byte stores into the next tile and into cat).  Weights: the 7 packed A-fragment images of mv_dconv_pack back to back.
+template <typename T, int CS>
+__global__ __launch_bounds__(256) void res2_chain_kernel(const T* __restrict__ u, const T* __restrict__ wp, const T* __restrict__ bias,
+                                                         T* __restrict__ cat, int T_, int C, int d) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int TT = 64, MT = CS / 16, KH = CS / 32, KS = 3 * KH, RS = CS * 2 + 16, PCS = CS / 8;
+  extern __shared__ __align__(16) char lds[];
+  const int P = TT + 14 * d + 16;
+  char* cur = lds;
+  char* nxt = lds + P * RS;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT, base = t0 - 7 * d;
+  const T* ub = u + (long)b * T_ * C;
+  T* cb = cat + (long)b * T_ * C;
+  for (int i = tid; i < P * PCS; i += 256) {           // in_1 = xs[1] + xs[0] (zero outside the sequence); cat[:, 0] = xs[0]
+    const int row = i / PCS, pc = i % PCS, p = base + row;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p >= 0 && p < T_) {
+      float a[8], c[8];
+      load8<T>(ub + (long)p * C + pc * 8, a);
+      load8<T>(ub + (long)p * C + CS + pc * 8, c);
+      if (p >= t0 && p < t0 + TT) store8<T>(cb + (long)p * C + pc * 8, a);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = a[e] + c[e];
+    }
+    store8<T>(reinterpret_cast<T*>(cur + row * RS + pc * 16), v);
+  }
+#pragma unroll 1
+  for (int i = 1; i <= 7; ++i) {
+    V a[MT][KS];
+    const T* wi = wp + (long)(i - 1) * CS * CS * 3;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) a[mt][ks] = M::load_b(wi + ((long)(mt * KS + ks) * 64 + lane) * 8);
+    float bv[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) M::load4(bias + (i - 1) * CS + 16 * mt + 4 * g, bv[mt]);
+    __syncthreads();                                    // in_i complete (staging / previous step), previous reads of `nxt` done
+    const int r0 = i * d, L = TT + 2 * (7 - i) * d, nct = (L + 15) / 16;
+    for (int ct = wid; ct < nct; ct += 4) {
+      const int row = r0 + 16 * ct + l15, p = base + row, pt0 = base + r0 + 16 * ct;
+      const bool live = pt0 < T_ && pt0 + 16 > 0;       // wave-uniform: tiles wholly outside the sequence are zeros
+      f32x4 acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live) {
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+          for (int kh = 0; kh < KH; ++kh) {
+            const V bf = M::load_b(cur + (row + (tap - 1) * d) * RS + (kh * 32 + g * 8) * 2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = M::mma(a[mt][tap * KH + kh], bf, acc[mt]);
+          }
+      }
+      const bool inreg = 16 * ct + l15 < L;
+      const bool valid = inreg && p >= 0 && p < T_;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = valid ? acc[mt][r] + bv[mt][r] : 0.f;
+        const int co = 16 * mt + 4 * g;
+        if (valid && p >= t0 && p < t0 + TT) M::store4(cb + (long)p * C + i * CS + co, o);
+        if (i < 7 && inreg) {
+          float nx[4] = {0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            float uu[4];
+            M::load4(ub + (long)p * C + (i + 1) * CS + co, uu);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nx[r] = uu[r] + o[r];
+          }
+          M::store4(nxt + row * RS + co * 2, nx);
+        }
+      }
+    }
+    char* t = cur; cur = nxt; nxt = t;
+  }
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -578,6 +666,23 @@ extern "C" int mv_gemm_cl_skinny(const void* x, const void* packed, const void* 
     rc = dtype == MV_BF16 ? skinny_launch<bf16>(x, packed, bias, y, M, K, N, f, st_) : skinny_launch<f16>(x, packed, bias, y, M, K, N, f, st_);
   }
   if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_res2_chain(const void* u, const void* packed, const void* bias, void* cat, int B, int T_, int C, int cs, int dil, int dtype,
+                             void* stream) {
+  MV_CHECK_ARG(u && packed && bias && cat && B > 0 && T_ > 0 && C > 0 && cs > 0 && dil >= 1 && B <= 65535);
+  MV_CHECK_ARG((((uintptr_t)u | (uintptr_t)packed | (uintptr_t)bias | (uintptr_t)cat) & 15) == 0);
+  if (dtype == MV_F32 || C != 8 * cs || (cs != 32 && cs != 64) || dil > 4) return MV_ERR_UNSUPPORTED;
+  const dim3 grid(cdiv(T_, 64), B);
+  const size_t ldsb = 2 * (size_t)(64 + 14 * dil + 16) * (cs * 2 + 16);
+  hipStream_t st_ = (hipStream_t)stream;
+#define MV_R2(TT, CS_) hipLaunchKernelGGL((res2_chain_kernel<TT, CS_>), grid, dim3(256), ldsb, st_, (const TT*)u, (const TT*)packed, (const TT*)bias, (TT*)cat, T_, C, dil)
+  if (dtype == MV_BF16) { if (cs == 64) MV_R2(bf16, 64); else MV_R2(bf16, 32); }
+  else if (dtype == MV_F16) { if (cs == 64) MV_R2(f16, 64); else MV_R2(f16, 32); }
+  else return MV_ERR_DTYPE;
+#undef MV_R2
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

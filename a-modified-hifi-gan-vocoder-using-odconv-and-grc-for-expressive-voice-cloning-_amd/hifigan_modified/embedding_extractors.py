@@ -30,6 +30,7 @@ from . import ops
 _RELU = (N.ACT_LRELU, 0.0)
 _NONE = (N.ACT_NONE, 0.0)
 _TANH = (N.ACT_TANH, 0.0)
+_UNFUSED_RES2 = False   # tests: force the conv-by-conv Res2Net chain
 _SKINNY_ROWS = 4096     # up to this many positions the split-K GEMM beats the tiled conv kernel (tools/bench_embed.py)
 
 
@@ -177,9 +178,15 @@ class SE_Res2Block(nn.Module):
         self._plan = _Plan()
 
     def _build(self, dtype):
-        return {"c1": _Affine(self.conv1.weight, self.conv1.bias, self.bn1, dtype),
-                "sc": [None] + [_Affine(c.weight, c.bias, None, dtype, self.dilation) for c in list(self.scale_convs)[1:]],
-                "c2": _Affine(self.conv2.weight, self.conv2.bias, self.bn2, dtype)}
+        convs = list(self.scale_convs)[1:]
+        plan = {"c1": _Affine(self.conv1.weight, self.conv1.bias, self.bn1, dtype),
+                "sc": [None] + [_Affine(c.weight, c.bias, None, dtype, self.dilation) for c in convs],
+                "c2": _Affine(self.conv2.weight, self.conv2.bias, self.bn2, dtype), "chain": None}
+        cs = self.channels // self.scale
+        if dtype != torch.float32 and self.scale == 8 and cs in (32, 64) and self.dilation <= 4:      # one launch for the whole chain
+            plan["chain"] = (torch.cat([ops.dconv_pack(c.weight.detach().unsqueeze(2), dtype, 0) for c in convs]),
+                             torch.stack([c.bias.detach() for c in convs]).to(dtype).contiguous())
+        return plan
 
     def forward_cl(self, x_cl: torch.Tensor) -> torch.Tensor:
         p = self._plan.get(self, x_cl.dtype, self._build)
@@ -189,6 +196,10 @@ class SE_Res2Block(nn.Module):
             raise RuntimeError(f"SE_Res2Block: channels/scale = {cs} must be a multiple of 8")
         u = p["c1"](x_cl, _RELU)
         cat = torch.empty_like(u)
+        if p["chain"] is not None and not _UNFUSED_RES2:
+            N.call("mv_res2_chain", ops._p(u), ops._p(p["chain"][0]), ops._p(p["chain"][1]), ops._p(cat), B, T, C, cs, self.dilation, dt,
+                   ops._stream())
+            return self.se.scale_add_cl(p["c2"](cat, _RELU), x_cl)
         nxt = torch.empty(B, T, cs, device=u.device, dtype=u.dtype)
         # ys[0] = xs[0]; input of conv 1 = xs[1] + ys[0]  (:137-141)
         N.call("mv_res2_glue", ops._p(u), C, ops._p(u), ops._p(cat), ops._p(nxt), rows, C, cs, 0, cs, dt, ops._stream())

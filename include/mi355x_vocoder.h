@@ -384,6 +384,12 @@ int mv_mha_fwd(const void* qkv, void* out, int B, int T, int nheads, int head_di
  * {1,2,3,4,6,8}, N % 64 == 0; otherwise MV_ERR_UNSUPPORTED (callers then use mv_dconv_cl_fwd). */
 int mv_gemm_cl_skinny(const void* x, const void* packed, const void* bias, void* y, int M, int K, int N, int act, float slope,
                       int dtype, void* stream);
+/* Fused Res2Net chain of SE_Res2Block (embedding_extractors.py:135-143): u, cat [B][T][8*cs]; cat[:, 0:cs] = u[:, 0:cs],
+ * cat[:, i] = conv_i(u[:, i] + cat[:, i-1]) for i = 1..7 (k = 3, dilation dil, 'same' zero padding).  packed = the 7
+ * mv_dconv_pack(w_i [cs][cs][1][3]) images back to back, bias [7][cs] in `dtype`.  16-bit storage, cs 32 or 64, dil <= 4;
+ * otherwise MV_ERR_UNSUPPORTED (callers then chain mv_dconv_cl_fwd + mv_res2_glue). */
+int mv_res2_chain(const void* u, const void* packed, const void* bias, void* cat, int B, int T, int C, int cs, int dil, int dtype,
+                  void* stream);
 
 #ifdef __cplusplus
 }

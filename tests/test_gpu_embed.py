@@ -187,3 +187,20 @@ def test_skinny_gemm_vs_fp64(H, dtype, M, K, N, act):
     assert rel_l2(y.double().cpu(), ref.cpu()) < {torch.float16: 1e-3, torch.bfloat16: 6e-3}[dtype]
     # unsupported shapes are refused, not mis-computed
     assert N_.lib().mv_gemm_cl_skinny(P(x), P(packed), P(b), P(y), M, K + 32, N, kind, 0.0, ops._dt(x), ops._stream()) == -3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("channels,dil,T", [(512, 4, 150), (512, 2, 64), (256, 3, 65), (512, 1, 7), (256, 4, 300)])
+def test_fused_res2_chain_matches_conv_by_conv(H, dtype, channels, dil, T):
+    from hifigan_modified import embedding_extractors as EE
+    m = build("res2", None, channels=channels, dilation=dil).cuda()
+    torch.manual_seed(T)
+    x = torch.randn(3, channels, T, device="cuda").to(dtype)
+    y = m(x)
+    EE._UNFUSED_RES2 = True
+    try:
+        y_ref = m(x)
+    finally:
+        EE._UNFUSED_RES2 = False
+    # the fused chain adds xs[i] + ys[i-1] in fp32 (one rounding), the launch-per-conv path rounds ys[i-1] first
+    assert rel_l2(y.float().cpu(), y_ref.float().cpu()) < {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
