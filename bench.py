@@ -29,7 +29,7 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None):
+def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None):
     """The CPU leg - the only place bench.py touches oracle/ (as the checker and the reported baseline, never as the thing
     measured).  `checks`: {name: (gpu waveform on the host, (mel, spk, emo) fp32 host inputs)} -> rel-L2 of each against the
     oracle, returned under "parity".
@@ -74,6 +74,21 @@ def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None):
         with torch.no_grad():
             for name, (wave, (m, sp, em)) in checks.items():
                 out["parity"][name] = O.rel_l2(wave, O.generator_forward(m, sd, "", sp, em))
+    if embed_check is not None:      # conditioning producers: oracle/embed_oracle.py as checker and as the CPU figure (bounded: <= 3 s)
+        from oracle import embed_oracle as E
+        esd, emel, spk_gpu, emo_gpu = embed_check
+        torch.set_num_threads(best["cores"])
+        with torch.no_grad():
+            spk_o, emo_o = E.embedding_extractor(emel, esd)
+            out.setdefault("parity", {})["conditioning"] = {"speaker": O.rel_l2(spk_gpu, spk_o), "emotion": O.rel_l2(emo_gpu, emo_o)}
+            m8 = torch.randn(8, 80, Tm)
+            E.embedding_extractor(m8, esd)
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 3.0 and n < 20:
+                E.embedding_extractor(m8, esd)
+                n += 1
+            out["conditioning"] = {"value": round(8 * Tm * n / (time.perf_counter() - t0), 1), "unit": "mel-frames/s", "cores": best["cores"],
+                                   "kind": "port", "sample": "%d forwards of B=8 x %d frames, fp32" % (n, Tm)}
     return out
 
 
@@ -120,6 +135,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conditioning", action="store_true", help="skip the embedding-extractor leg")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
     ap.add_argument("--train-warmup", type=int, default=2)
@@ -292,6 +308,50 @@ def main():
                                             "parity_rel_l2_vs_oracle": None}
             del gv16, g16
 
+    # ---------------------------------------------------------------- conditioning producers
+    # ECAPA-TDNN + Emotion2Vec on the same mel batch (what ModifiedHiFiGANVocoder.forward(extract_embeddings=True) runs in front
+    # of the generator): throughput of the captured forward, the dominant kernel's roofline, parity against the CPU oracle.
+    conditioning, embed_check = None, None
+    if rank == 0 and world == 1 and dtype != torch.float32 and not args.eager and not args.no_conditioning:
+        from hifigan_modified.graphs import GraphedExtractor
+        from hifigan_modified import ops as _ops, _native as _N
+        torch.manual_seed(0)
+        ex = H.EmbeddingExtractor().to(dev).train(False)
+        with torch.no_grad():
+            for bn in [m for m in ex.modules() if isinstance(m, torch.nn.BatchNorm1d)]:      # non-trivial running statistics
+                bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+            s2, e2 = ex(mel[:2])
+        embed_check = ({k: v.detach().float().cpu() for k, v in ex.state_dict().items()}, mel[:2].float().cpu(), s2.float().cpu(), e2.float().cpu())
+        ge = GraphedExtractor(ex, mel)
+        for _ in range(20):
+            ge.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nE = 200
+        for _ in range(nE):
+            ge.replay()
+        torch.cuda.synchronize()
+        elE = time.perf_counter() - t1
+        # dominant kernel: the split-K GEMM of the 512 -> 512 layers (27 of ~80 launches per forward)
+        Mr, Kd, Nd = B * Tm, 512, 512
+        xg = torch.randn(Mr, Kd, device=dev).to(dtype)
+        wg = _ops.dconv_pack((torch.randn(Nd, Kd, 1, 1, device=dev) / Kd ** 0.5), dtype, 0)
+        bg = torch.zeros(Nd, device=dev, dtype=dtype)
+        yg = torch.empty(Mr, Nd, device=dev, dtype=dtype)
+        run = lambda: _N.call("mv_gemm_cl_skinny", _ops._p(xg), _ops._p(wg), _ops._p(bg), _ops._p(yg), Mr, Kd, Nd, _N.ACT_LRELU, 0.0,
+                              _ops._dt(xg), _ops._stream())
+        msg = graph_time_ms(run)
+        gb = (Mr * Kd + Nd * Kd + Mr * Nd) * 2
+        conditioning = {"metric": "mel-frames/s embedded (ECAPA-TDNN speaker + Emotion2Vec emotion encoders)",
+                        "value": round(B * Tm * nE / elE, 1), "unit": "mel-frames/s", "ms_per_step": round(elE / nE * 1e3, 4), "dtype": args.dtype,
+                        "launch": "hipgraph", "parity_rel_l2_vs_oracle": None,
+                        "roofline": {"bound": "hbm", "kernel": "mv::gemm_skinny_kernel<%s,2> (%dx%dx%d, split-K over 8 waves)" % (args.dtype, Mr, Nd, Kd),
+                                     "achieved": round(gb / (msg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(gb / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": gb,
+                                     "ms_per_launch": round(msg, 4),
+                                     "note": "launch/latency-bound at %d rows: ~80 dependent launches of <= 10 us per forward" % Mr}}
+        del ge, ex
+
     # ---------------------------------------------------------------- training metric (BASELINE configs[2]/[3])
     # full two-optimizer step (complete_vocoder.py:199-233): G forward -> D step -> G step, + mel/STFT loss, + AdamW;
     # data parallel: 32 clips per GPU, one all-reduce of the flat gradient buffer per optimizer step (RCCL)
@@ -372,10 +432,14 @@ def main():
             "roofline_odconv": od_roof,
             "parity_grade": parity_grade,
             "train": train,
+            "conditioning": conditioning,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks)
+            cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks, embed_check=embed_check)
             par = cb.pop("parity", {})
+            if conditioning is not None:
+                conditioning["parity_rel_l2_vs_oracle"] = par.get("conditioning")
+                conditioning["cpu_baseline"] = cb.pop("conditioning", None)
             out["parity_rel_l2_vs_oracle"] = par.get("headline")
             if parity_grade is not None:
                 parity_grade["parity_rel_l2_vs_oracle"] = par.get("parity_grade")
