@@ -265,10 +265,14 @@ class ECAPA_TDNN(nn.Module):
         return pooled
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    def embed(self, x: torch.Tensor) -> torch.Tensor:
         pooled = self.pooled_cl(x)
         fw, fb = self._plan.items["final"]
-        emb = _l2norm(ops.linear(pooled, fw, fb), x.dtype)
+        return _l2norm(ops.linear(pooled, fw, fb), x.dtype)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        emb = self.embed(x)
         if self.training:
             c = self.speaker_classifier
             return emb, ops.linear(emb, ops.cast(c.weight.detach(), emb.dtype), ops.cast(c.bias.detach(), emb.dtype))
@@ -276,7 +280,9 @@ class ECAPA_TDNN(nn.Module):
 
 
 class Emotion2Vec(nn.Module):
-    """embedding_extractors.py:172-257.  forward(mel) -> (frame embeddings [B,T,E], utterance embedding [B,E], logits|None)."""
+    """embedding_extractors.py:172-257.  forward(mel) -> (frame embeddings [B,T,E], utterance embedding [B,E], logits|None).
+    In `.train()` mode the reference feeds the [B, embedding_dim] utterance embedding to `Linear(hidden_dim, .)` (:250 vs :209): a shape
+    error unless the two sizes agree.  Reproduced as a RuntimeError."""
 
     def __init__(self, input_dim: int = 80, hidden_dim: int = 512, embedding_dim: int = 256, num_emotions: int = 8):
         super().__init__()
@@ -337,12 +343,20 @@ class Emotion2Vec(nn.Module):
             f = self._add_ln(L["ff2"](L["ff1"](f, _RELU), _NONE), f, L["n2"])
         return f
 
+    def _utterance(self, f, dtype):
+        up = self.utterance_projection
+        return _l2norm(ops.linear(_mean_t(f), up.weight.detach().float(), up.bias.detach().float()), dtype)
+
+    @torch.no_grad()
+    def embed(self, x: torch.Tensor) -> torch.Tensor:
+        """Utterance-level embedding only (what EmbeddingExtractor consumes): no frame projection, no classifier head."""
+        return self._utterance(self.encode_cl(x), x.dtype)
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         f = self.encode_cl(x)
         frame = self._plan.items["frame"](f, _NONE)
-        up = self.utterance_projection
-        utt = _l2norm(ops.linear(_mean_t(f), up.weight.detach().float(), up.bias.detach().float()), x.dtype)
+        utt = self._utterance(f, x.dtype)
         if self.training:
             c0, c3 = self.emotion_classifier[0], self.emotion_classifier[3]
             cast = lambda t: ops.cast(t.detach(), utt.dtype)
@@ -361,6 +375,6 @@ class EmbeddingExtractor(nn.Module):
 
     @torch.no_grad()
     def forward(self, mel_spectrogram: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        spk = self.speaker_extractor(mel_spectrogram)[0]
-        emo = self.emotion_extractor(mel_spectrogram)[1]
-        return spk, emo
+        # the reference discards the classifier logits and the frame embeddings here (:277-282); they are not computed at all, which
+        # also keeps `.train()` mode usable (Emotion2Vec.forward raises there, as the reference's does: see the class docstring)
+        return self.speaker_extractor.embed(mel_spectrogram), self.emotion_extractor.embed(mel_spectrogram)

@@ -204,3 +204,20 @@ def test_fused_res2_chain_matches_conv_by_conv(H, dtype, channels, dil, T):
         EE._UNFUSED_RES2 = False
     # the fused chain adds xs[i] + ys[i-1] in fp32 (one rounding), the launch-per-conv path rounds ys[i-1] first
     assert rel_l2(y.float().cpu(), y_ref.float().cpu()) < {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+
+
+def test_trainer_step_without_embeddings_uses_the_extractor(H):
+    """complete_vocoder.py:207: VocoderTrainer.train_step calls self.vocoder(mel) with no embeddings -> extracted ones condition
+    the generator; the frozen extractor is not touched by either optimizer."""
+    torch.manual_seed(0)
+    voc = H.ModifiedHiFiGANVocoder(hidden_channels=64)
+    tr = H.VocoderTrainer(voc, device=torch.device("cuda"))
+    before = {k: v.detach().clone() for k, v in voc.embedding_extractor.state_dict().items()}
+    torch.manual_seed(1)
+    mel = torch.randn(2, 80, 8, device="cuda")
+    real = torch.randn(2, 1, 8 * 256, device="cuda").clamp(-1, 1)
+    out = tr.train_step(mel, real)
+    assert all(torch.isfinite(torch.tensor(float(v))) for v in out.values())
+    after = voc.embedding_extractor.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    assert all(p.grad is None for p in voc.embedding_extractor.parameters())
