@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void odconv_attn_pooled_kernel(const float* __r
 // proj = W . cond + b with cond = cat(spk, emo) truncated / zero-padded to the projection's input width (grc_lora.py:82-105),
 // (4) zeroing of this sample's share of the pooled-sum buffers the upsamplers accumulate into.
 template <typename T>
-__global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
+__global__ __launch_bounds__(1024) void gen_prologue_kernel(const T* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
                                                            const T* __restrict__ spk, const T* __restrict__ emo, const T* __restrict__ film_w,
                                                            const T* __restrict__ film_b, float* __restrict__ alpha, T* __restrict__ x_cl,
                                                            T* __restrict__ film_proj, float* __restrict__ zero_buf, long zero_n, int C,
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
   float* mean = xs + C * Tn;
   float* logit = mean + C;
   float* cond = logit + K;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x, nw = nt >> 6;
   const T* xb = mel + (long)b * C * Tn;
-  for (int i = tid; i < C * Tn; i += 256) xs[i] = ld<T>(xb + i);
-  for (int i = tid; i < cond_dim; i += 256) {
+  for (int i = tid; i < C * Tn; i += nt) xs[i] = ld<T>(xb + i);
+  for (int i = tid; i < cond_dim; i += nt) {
     float v = 0.f;
     if (i < ds) v = ld<T>(spk + (long)b * ds + i);
     else if (i < ds + de) v = ld<T>(emo + (long)b * de + (i - ds));
@@ -114,18 +114,18 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
   {
     const long per = (zero_n + gridDim.x - 1) / gridDim.x, z0 = (long)b * per;
     const long z1 = z0 + per < zero_n ? z0 + per : zero_n;
-    for (long i = z0 + tid; i < z1; i += 256) zero_buf[i] = 0.f;
+    for (long i = z0 + tid; i < z1; i += nt) zero_buf[i] = 0.f;
   }
   __syncthreads();
   // channels-last copy
   T* yb = x_cl + (long)b * Tn * C;
-  for (int i = tid; i < C * Tn; i += 256) {
+  for (int i = tid; i < C * Tn; i += nt) {
     const int t = i / C, c = i - t * C;
     st<T>(yb + i, xs[c * Tn + t]);
   }
   // attention
   const float inv = 1.f / (float)Tn;
-  for (int c = wid; c < C; c += 4) {
+  for (int c = wid; c < C; c += nw) {
     float a = 0.f;
     for (int t = lane; t < Tn; t += 64) a += xs[c * Tn + t];
     a = wave_sum(a);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
   if (film_proj) {
     constexpr int EPV = 16 / sizeof(T);
     const bool vec = sizeof(T) == 2 && cond_dim % EPV == 0 && ((uintptr_t)film_w & 15) == 0;
-    for (int j0 = wid * 4; j0 < F2; j0 += 16) {
+    for (int j0 = wid * 4; j0 < F2; j0 += 4 * nw) {
       float a[4] = {0.f, 0.f, 0.f, 0.f};
       if (vec) {
         for (int pc = lane; pc < cond_dim / EPV; pc += 64) {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void gen_prologue_kernel(const T* __restrict__
     }
   }
   __syncthreads();
-  for (int k = wid; k < K; k += 4) {
+  for (int k = wid; k < K; k += nw) {
     float a = 0.f;
     for (int c = lane; c < C; c += 64) a += ld<T>(att_w + (long)k * C + c) * mean[c];
     a = wave_sum(a);
@@ -483,7 +483,7 @@ extern "C" int mv_gen_prologue(const void* mel, const void* att_w, const void* a
   MV_CHECK_ARG((ds == 0 || spk) && (de == 0 || emo) && (!film_proj || (film_w && cond_dim > 0 && F2 > 0)) && (zero_n == 0 || zero_buf));
   const size_t lds = sizeof(float) * ((size_t)C * T_ + C + K + (film_proj ? cond_dim : 0));
   if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;   // long inputs: the caller issues the separate launches
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B), dim3(256), lds, (hipStream_t)stream, (const T*)mel,
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B), dim3(1024), lds, (hipStream_t)stream, (const T*)mel,
                                         (const T*)att_w, (const T*)att_b, (const T*)spk, (const T*)emo, (const T*)film_w,
                                         (const T*)film_b, alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, C, T_, K, ds, de,
                                         film_proj ? cond_dim : 0, F2));
