@@ -245,6 +245,8 @@ class ECAPA_TDNN(nn.Module):
 
     def pooled_cl(self, x: torch.Tensor) -> torch.Tensor:
         """mel [B, C, T] -> attentive statistics [B, 6*hidden] (fp32)."""
+        if x.dim() != 3 or x.shape[1] != self.input_dim:
+            raise RuntimeError(f"ECAPA_TDNN expects a mel-spectrogram [B, {self.input_dim}, T], got {tuple(x.shape)}")
         p = self._plan.get(self, x.dtype, self._build)
         B, _, T = x.shape
         if T < 6:
@@ -328,6 +330,8 @@ class Emotion2Vec(nn.Module):
 
     def encode_cl(self, x: torch.Tensor) -> torch.Tensor:
         """mel [B, C, T] -> transformer output [B, T, hidden] (channels-last)."""
+        if x.dim() != 3 or x.shape[1] != self.input_dim:
+            raise RuntimeError(f"Emotion2Vec expects a mel-spectrogram [B, {self.input_dim}, T], got {tuple(x.shape)}")
         p = self._plan.get(self, x.dtype, self._build)
         c0 = p["convs"][0]
         f = _mel_to_cl(x, c0.cinp if c0.mfma else None)

@@ -221,3 +221,43 @@ def test_trainer_step_without_embeddings_uses_the_extractor(H):
     after = voc.embedding_extractor.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before)
     assert all(p.grad is None for p in voc.embedding_extractor.parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_long_batch_takes_the_tiled_gemm_path_and_matches_the_oracle(H, dtype):
+    """B*T > 4096 positions: the k=1 layers run on the tiled MFMA conv kernel (flattened over the batch) instead of the split-K GEMM.
+    Samples are independent, so the first two rows of the big batch must match the CPU oracle on those two samples alone."""
+    from oracle import embed_oracle as E
+    m = build("extractor", None).cuda()
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    torch.manual_seed(5)
+    mel = torch.randn(16, 80, 300, device="cuda")
+    spk, emo = m(mel.to(dtype))
+    spk_o, emo_o = E.embedding_extractor(mel[:2].cpu(), sd)
+    assert rel_l2(spk[:2].float().cpu(), spk_o) < TOL[dtype] and rel_l2(emo[:2].float().cpu(), emo_o) < 2 * TOL[dtype]
+    # and the same samples through the short-sequence path agree with the long-batch result
+    spk_s, emo_s = m(mel[:2].to(dtype))
+    assert rel_l2(spk_s.float().cpu(), spk[:2].float().cpu()) < TOL[dtype]
+    assert rel_l2(emo_s.float().cpu(), emo[:2].float().cpu()) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_extractor_edge_shapes(H, dtype):
+    from oracle import embed_oracle as E
+    torch.manual_seed(9)
+    emo_m = build("emotion", None, hidden_dim=128).cuda()
+    sd = {k: v.detach().float().cpu() for k, v in emo_m.state_dict().items()}
+    for B, T in [(1, 1), (1, 2), (3, 65)]:                     # single frame, single sample, one past the attention key block
+        x = torch.randn(B, 80, T)
+        fr, ut, _ = emo_m(x.cuda().to(dtype))
+        fr_o, ut_o = E.emotion2vec(x, sd)
+        assert fr.shape == (B, T, 256) and rel_l2(fr.float().cpu(), fr_o) < 2 * TOL[dtype], (B, T)
+        assert rel_l2(ut.float().cpu(), ut_o) < 2 * TOL[dtype], (B, T)
+    spk_m = build("ecapa", None, hidden_dim=256, num_speakers=4).cuda()
+    sd = {k: v.detach().float().cpu() for k, v in spk_m.state_dict().items()}
+    for B, T in [(1, 6), (2, 7), (1, 129)]:                    # shortest legal input (2 frames after the valid conv), tile edges
+        x = torch.randn(B, 80, T)
+        e = spk_m(x.cuda().to(dtype))[0]
+        assert rel_l2(e.float().cpu(), E.ecapa_tdnn(x, sd)) < 3 * TOL[dtype], (B, T)
+    with pytest.raises(RuntimeError):
+        spk_m(torch.randn(2, 80, device="cuda"))               # not [B, C, T]
