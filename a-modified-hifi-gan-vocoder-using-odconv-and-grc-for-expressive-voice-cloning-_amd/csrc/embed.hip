@@ -271,27 +271,44 @@ __global__ __launch_bounds__(256) void mha_kernel(const T* __restrict__ qkv, T* 
   for (int i = 0; i < DT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mrun = -3.0e38f, lrun = 0.f;
 
+  // K / V pieces of a key block travel global -> registers one block ahead of their use (unconditional, row-clamped loads: the
+  // fetch of block kb+1 is in flight under the MFMAs of block kb), registers -> LDS at the top of the block
+  constexpr int PCS = HD / 8;                            // 16-byte pieces per key row
+  constexpr int NPT = (KB * PCS + 255) / 256;            // pieces per thread
+  uint4 kreg[NPT], vreg[NPT];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const int i = tid + j * 256;
+      const int key = (i / PCS) % KB, pc = i % PCS;
+      int kr = kb + key; if (kr >= T_) kr = T_ - 1;
+      const T* rowp = base + (long)kr * rs + pc * 8;
+      kreg[j] = *reinterpret_cast<const uint4*>(rowp + H);
+      vreg[j] = *reinterpret_cast<const uint4*>(rowp + 2 * H);
+    }
+  };
+  fetch(0);
   for (int kb = 0; kb < T_; kb += KB) {
     __syncthreads();
     // stage K (row-major, zero rows past T, zero pad columns) and V^T
-    constexpr int PCS = HD / 8;                          // 16-byte pieces per key row
-    for (int i = tid; i < KB * PCS; i += 256) {
-      const int key = i / PCS, pc = i % PCS;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-      if (kb + key < T_) {
-        const T* rowp = base + (long)(kb + key) * rs + pc * 8;
-        kv = *reinterpret_cast<const uint4*>(rowp + H);
-        vv = *reinterpret_cast<const uint4*>(rowp + 2 * H);
-      }
-      *reinterpret_cast<uint4*>(kl + key * KRS + pc * 16) = kv;
-      if (HD < HDP && pc == 0) {
 #pragma unroll
-        for (int z = HD / 8; z < HDP / 8; ++z) *reinterpret_cast<uint4*>(kl + key * KRS + z * 16) = make_uint4(0, 0, 0, 0);
-      }
-      const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
+    for (int j = 0; j < NPT; ++j) {
+      const int i = tid + j * 256;
+      if (i < KB * PCS) {
+        const int key = i / PCS, pc = i % PCS;
+        const bool ok = kb + key < T_;
+        const uint4 kv = ok ? kreg[j] : make_uint4(0, 0, 0, 0), vv = ok ? vreg[j] : make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(kl + key * KRS + pc * 16) = kv;
+        if (HD < HDP && pc == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(vl + (pc * 8 + e) * VRS + key * 2) = ve[e];
+          for (int z = HD / 8; z < HDP / 8; ++z) *reinterpret_cast<uint4*>(kl + key * KRS + z * 16) = make_uint4(0, 0, 0, 0);
+        }
+        const uint16_t* ve = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *reinterpret_cast<uint16_t*>(vl + (pc * 8 + e) * VRS + key * 2) = ve[e];
+      }
     }
+    fetch(kb + KB < T_ ? kb + KB : kb);
     __syncthreads();
 #pragma unroll
     for (int sb = 0; sb < KB; sb += 32) {

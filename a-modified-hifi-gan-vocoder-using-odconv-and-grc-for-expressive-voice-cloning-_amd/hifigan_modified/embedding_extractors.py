@@ -31,7 +31,7 @@ _RELU = (N.ACT_LRELU, 0.0)
 _NONE = (N.ACT_NONE, 0.0)
 _TANH = (N.ACT_TANH, 0.0)
 _UNFUSED_RES2 = False   # tests: force the conv-by-conv Res2Net chain
-_SKINNY_ROWS = 4096     # up to this many positions the split-K GEMM beats the tiled conv kernel (tools/bench_embed.py)
+_SKINNY_ROWS = int(__import__("os").environ.get("MV_SKINNY_ROWS", "4096"))     # up to this many positions the split-K GEMM beats the tiled conv kernel (tools/bench_embed.py)
 
 
 def _sig(mod: nn.Module):
