@@ -387,6 +387,226 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------ multi-tile variant
+// The last upsamplers (ODConvTranspose1d with ks = 2*stride, 64/128 input channels, small banks, long sequences): one workgroup
+// walks TL consecutive 128-column tiles of ONE sample.  What the one-tile kernel redoes per tile is done once per workgroup: the
+// attention softmax, the alpha-mixed bias and - the expensive part - the alpha mix of the K bank fragments (all KST k-steps of a
+// wave's rows stay in registers as ready A operands).  The x tile of the NEXT step travels global -> registers under the MFMAs of
+// the current one (unconditional, row-clamped loads) and is committed to LDS after the current tile's stores, so no global-load
+// latency sits on the per-tile path.  16-bit storage, LeakyReLU / none, no FiLM.
+template <typename T, int MW, int NB, int CIN, int KB>
+__global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
+                                                           const float* __restrict__ alpha_in, const float* __restrict__ pooled_in,
+                                                           const T* __restrict__ att_w, const T* __restrict__ att_b, T* __restrict__ y,
+                                                           float* __restrict__ pooled_out, OdP p, int TL) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  using WL = WLoad<T>;
+  constexpr int ES = 2, NTAPS = 2, CPR = CIN * ES / 16, CPC = CIN / 8, KST = NTAPS * CIN / 32;
+  constexpr int NROWS = NB * 16 + NTAPS - 1, PER = NROWS * CPR, XP = (PER + 255) / 256;
+  constexpr int RW = 4 * MW * 16, ORS = RW * ES + 16;
+  extern __shared__ __align__(16) char lds[];
+  float* alds = reinterpret_cast<float*>(lds);                 // [OD_MAXK]
+  float* bias_l = alds + OD_MAXK;                              // [RW]
+  char* xl = reinterpret_cast<char*>(bias_l + RW);
+  const int RS = lds_row_stride(CIN * ES, ES);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 15, g = lane >> 4;
+  const int mt0 = (blockIdx.y * 4 + wid) * MW, b = blockIdx.z, n_mt = p.M / 16, R0 = blockIdx.y * RW;
+
+  if (alpha_in) {
+    if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+  } else {
+    for (int kb = wid; kb < p.K; kb += 4) {
+      float a = 0.f;
+      for (int c = lane; c < CIN; c += 64) a += ld<T>(att_w + (long)kb * CIN + c) * pooled_in[(long)b * CIN + c];
+      a = wave_sum(a);
+      if (lane == 0) alds[kb] = a / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float m = -INFINITY, den = 0.f;
+      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[kb]);
+      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[kb] - m);
+      for (int kb = 0; kb < p.K; ++kb) alds[kb] = expf(alds[kb] - m) / den;
+    }
+  }
+  // x tile prefetch registers: piece i = tid + 256 j of the [NROWS][CPR] tile
+  uint4 xreg[XP];
+  const char* xb = reinterpret_cast<const char*>(x + (long)b * p.Tin * CIN);
+  auto xfetch = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      int i = tid + j * 256; if (i >= PER) i = PER - 1;
+      const int r = i / CPR, ch = i % CPR;
+      int tin = q0 + p.shift_lo + r; tin = tin < 0 ? 0 : (tin >= p.Tin ? p.Tin - 1 : tin);
+      xreg[j] = *reinterpret_cast<const uint4*>(xb + ((long)tin * CIN) * ES + ch * 16);
+    }
+  };
+  auto xcommit = [&](int q0) {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int i = tid + j * 256;
+      if (i < PER) {
+        const int r = i / CPR, ch = i % CPR, tin = q0 + p.shift_lo + r;
+        *reinterpret_cast<uint4*>(xl + r * RS + ch * 16) = (tin >= 0 && tin < p.Tin) ? xreg[j] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  const int tile0 = blockIdx.x * TL;
+  xfetch(tile0 * NB * 16);
+  __syncthreads();                                             // alpha visible
+  if (bias) {
+    for (int i = tid; i < RW; i += 256) {
+      const int row = R0 + i;
+      const int o = row < p.M ? row % p.Cout : 0;
+      float v[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) v[kb] = ld<T>(bias + (long)(kb < p.K ? kb : 0) * p.Cout + o);
+      float a = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) a += (kb < p.K ? alds[kb] : 0.f) * v[kb];
+      bias_l[i] = a;
+    }
+  }
+  // this sample's kernel, once: A[mw][kstep] = sum_kb alpha[kb] * W[kb] fragments
+  V afr[MW][KST];
+  {
+    float al[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) al[kb] = kb < p.K ? alds[kb] : 0.f;
+    const long bank_stride = (long)n_mt * KST * 512 * ES;
+    const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 8 * ES;
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+#pragma unroll
+      for (int ks = 0; ks < KST; ++ks) {
+        typename WL::R wr[KB];
+        const char* wbase = wlane + ((long)mt * KST + ks) * 512 * ES;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) wr[kb] = WL::load(wbase + (kb < p.K ? kb : 0) * bank_stride);
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) WL::fma8(wr[kb], al[kb], f);
+        afr[mw][ks] = make_a<T>(f);
+      }
+    }
+  }
+  const ActLrelu actf{p.act == ACT_NONE ? 1.f : p.slope};
+  float psum[MW][4];
+#pragma unroll
+  for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) psum[mw][i] = 0.f;
+
+  for (int t = 0; t < TL; ++t) {
+    const int q0 = (tile0 + t) * NB * 16;
+    if (q0 >= p.nq) break;
+    xcommit(q0);
+    {
+      const int qn = q0 + NB * 16;
+      xfetch(qn < p.nq && t + 1 < TL ? qn : q0);               // always issued: a branch around it would drain the queue first
+    }
+    __syncthreads();
+    f32x4 acc[MW][NB];
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      const int chunk = 4 * ks + g, tap = chunk / CPC, c8 = chunk % CPC;
+      const int bbase = (-tap - p.shift_lo + col) * RS + c8 * 8 * ES;
+      V bfr[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) bfr[n] = M::load_b(xl + bbase + n * 16 * RS);
+#pragma unroll
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(afr[mw][ks], bfr[n], acc[mw][n]);
+    }
+    __syncthreads();                                           // x tile consumed: reuse the region as the output tile
+    char* ol = xl;
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
+      if (mt < n_mt) {
+        const int row = 16 * mt + 4 * g;
+        const int r = row / p.Cout;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) { const f32x4 bl = *reinterpret_cast<const f32x4*>(bias_l + (row - R0)); bv[0] = bl[0]; bv[1] = bl[1]; bv[2] = bl[2]; bv[3] = bl[3]; }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const int q = q0 + n * 16 + col;
+          const int u = q * p.stride + r - p.pad;
+          const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+          float ov[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            ov[i] = actf(acc[mw][n][i] + bv[i]);
+            if (ok) psum[mw][i] += M::round_store(ov[i]);
+          }
+          M::store4(ol + ((long)(n * 16 + col)) * ORS + (row - R0) * ES, ov);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      constexpr int EPC = 16 / ES, CPRO = RW / EPC;
+      static_assert(256 % CPRO == 0, "store loop: fixed column per thread");
+      const int ch = tid % CPRO, row = R0 + ch * EPC;
+      const int r = row / p.Cout, o = row % p.Cout;
+      if (row < p.M)
+        for (int e = tid / CPRO; e < NB * 16; e += 256 / CPRO) {
+          const int q = q0 + e;
+          const int u = q * p.stride + r - p.pad;
+          if (q >= p.nq || u < 0 || u >= p.Tout) continue;
+          const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)e) * ORS + ch * 16);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
+        }
+    }
+    __syncthreads();                                           // output tile drained before the next x tile lands
+  }
+  if (pooled_out) {                                            // one atomic per (row, workgroup) instead of one per tile
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = psum[mw][i];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (col == 0 && mt < n_mt) atomicAdd(pooled_out + (long)b * p.Cout + (16 * mt + 4 * g + i) % p.Cout, v);
+      }
+    }
+  }
+}
+
+template <typename T, int MW, int NB, int CIN>
+static int od_mt_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
+                        const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream) {
+  constexpr int ES = 2;
+  const int nrows = NB * 16 + 1;
+  const size_t xbytes = (size_t)nrows * lds_row_stride(CIN * ES, ES);
+  const size_t obytes = (size_t)NB * 16 * (4 * MW * 16 * ES + 16);
+  const size_t lds = sizeof(float) * (OD_MAXK + 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
+  if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
+  const int ntl = cdiv(p.nq, NB * 16);
+  const int gy = cdiv(p.M / 16, 4 * MW);
+  // about two workgroups per CU: enough to overlap each other's barriers, few enough to amortise the per-workgroup weight mix
+  static int tgt = -1;
+  if (tgt < 0) { const char* e = getenv("MV_OD_MT_WGS"); tgt = e ? atoi(e) : 512; }
+  int TL = (int)(((long)ntl * gy * p.B + tgt - 1) / tgt);
+  if (TL < 1) TL = 1;
+  if (TL > 16) TL = 16;
+  dim3 grid(cdiv(ntl, TL), gy, p.B);
+  if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((odconv_cl_mt_kernel<T, MW, NB, CIN, 4>), grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha,
+                     pooled_in, (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p, TL);
+  return MV_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ K-loop variant
 // Short sequences with big kernel banks (the first upsampler: 33 columns per sample, 16.8 MB of banks): aggregating the
 // per-sample kernel costs more than the convolution itself.  Here the banks are used AS STORED - exactly the reference's
@@ -788,7 +1008,18 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
       OD_GO(1, 2, 9);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else {                                 // small kernels, long sequences: HBM-streaming regime
-      OD_GO(1, 2, 8);
+      rc = MV_ERR_UNSUPPORTED;
+      if constexpr (sizeof(T) == 2) {
+        static int mt_on = -1;
+        if (mt_on < 0) { const char* e = getenv("MV_OD_MT"); mt_on = e ? atoi(e) : 1; }
+        if (mt_on && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && (Cin == 64 || Cin == 128)) {
+          // 128-column tiles for 64 input channels; 64-column tiles for 128 (8 resident A fragments per M-tile: the wider tile
+          // would need > 256 VGPRs, i.e. one wave per SIMD - measured 42 vs 24.5 us)
+          if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+          else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+        }
+      }
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 8);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     }
   });
