@@ -51,6 +51,70 @@ __global__ void conv_out_pack_kernel(const P* __restrict__ w, float* __restrict_
   if (i < C * ks) { const int j = i / C, c = i % C; wt[i] = ld<P>(w + c * ks + j); }
 }
 
+
+// 16-bit storage: the same sliding dot product on v_dot2c_f32_{bf16,f16} (two MACs per lane and instruction, fp32 accumulate, no
+// unpacking).  The VALU form above spends 4 instructions per 2 MACs (2 converts + 2 FMAs) and is VALU-bound at 16.6 us for the
+// 33.5 MB it reads; here a lane reads 16 bytes of its row (4 channel pairs) per LDS access and the weight pairs arrive as
+// wave-uniform scalar loads from a pre-packed image in the activation type.
+template <typename T> struct Dot2;
+template <> struct Dot2<bf16> {
+  static __device__ __forceinline__ float f(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+template <> struct Dot2<f16> {
+  static __device__ __forceinline__ float f(uint32_t a, uint32_t b, float c) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void conv_out_dot2_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpairs, float bias,
+                                                            T* __restrict__ y, int Tn, int ks, int pad, int act) {
+  constexpr int ES = 2, RS = C * ES + 16, CPR = C * ES / 16;
+  extern __shared__ __align__(16) char lds[];
+  const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int rows = 256 + ks - 1;
+  const T* xb = x + (size_t)b * Tn * C;
+  stage_batched<9, 256>(tid, rows * CPR, lds, [&](int i, const void*& src, int& dst) {
+    const int r = i / CPR, ch = i % CPR;
+    const int t = t0 - pad + r;
+    if (t >= 0 && t < Tn) src = reinterpret_cast<const char*>(xb + (size_t)t * C) + ch * 16;
+    dst = r * RS + ch * 16;
+  });
+  __syncthreads();
+  float acc0 = bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  for (int j = 0; j < ks; ++j) {
+    const char* row = lds + (size_t)(tid + j) * RS;
+    const uint32_t* wj = wpairs + j * (C / 2);                // wave-uniform
+#pragma unroll
+    for (int c8 = 0; c8 < CPR; ++c8) {
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(row + c8 * 16);
+      acc0 = Dot2<T>::f(xv[0], wj[c8 * 4 + 0], acc0);
+      acc1 = Dot2<T>::f(xv[1], wj[c8 * 4 + 1], acc1);
+      acc2 = Dot2<T>::f(xv[2], wj[c8 * 4 + 2], acc2);
+      acc3 = Dot2<T>::f(xv[3], wj[c8 * 4 + 3], acc3);
+    }
+  }
+  const int t = t0 + tid;
+  if (t < Tn) st<T>(y + (size_t)b * Tn + t, apply_act((acc0 + acc1) + (acc2 + acc3), act, 0.f));
+}
+
+// all three images of w [1][C][ks]: fp32 [ks][C] | bf16 [ks][C] | f16 [ks][C]
+template <typename P>
+__global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restrict__ out, int C, int ks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * ks) {
+    const int j = i / C, c = i % C;
+    const float v = ld<P>(w + c * ks + j);
+    reinterpret_cast<float*>(out)[i] = v;
+    st<bf16>(reinterpret_cast<bf16*>(out + (size_t)C * ks * 4) + i, v);
+    st<f16>(reinterpret_cast<f16*>(out + (size_t)C * ks * 6) + i, v);
+  }
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -81,6 +145,41 @@ extern "C" int mv_conv_out_act_cl(const void* x, const float* wt, float bias, vo
     if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, wt, bias, (T*)y, T_, ks, pad, act);
   });
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" size_t mv_conv_out_packed_bytes(int C, int ks) { return (size_t)C * ks * 8; }
+
+extern "C" int mv_conv_out_pack_all(const void* w, int param_dtype, void* packed, int C, int ks, void* stream) {
+  MV_CHECK_ARG(w && packed && C > 0 && ks > 0 && ((uintptr_t)packed & 15) == 0 && (C * ks) % 8 == 0);
+  const dim3 g(cdiv(C * ks, 256)), b(256);
+  switch (param_dtype) {
+    case MV_F32: hipLaunchKernelGGL(conv_out_pack_all_kernel<float>, g, b, 0, (hipStream_t)stream, (const float*)w, (char*)packed, C, ks); break;
+    case MV_BF16: hipLaunchKernelGGL(conv_out_pack_all_kernel<bf16>, g, b, 0, (hipStream_t)stream, (const bf16*)w, (char*)packed, C, ks); break;
+    case MV_F16: hipLaunchKernelGGL(conv_out_pack_all_kernel<f16>, g, b, 0, (hipStream_t)stream, (const f16*)w, (char*)packed, C, ks); break;
+    default: return MV_ERR_DTYPE;
+  }
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_conv_out_act_packed_cl(const void* x, const void* packed, float bias, void* y, int B, int T_, int C, int ks, int pad,
+                                         int act, int dtype, void* stream) {
+  MV_CHECK_ARG(x && packed && y && B > 0 && B <= 65535 && T_ > 0 && ks > 0 && pad >= 0 && ((uintptr_t)x & 15) == 0);
+  if (C != 64 || 2 * pad != ks - 1) return MV_ERR_UNSUPPORTED;
+  const char* pk = (const char*)packed;
+  if (dtype == MV_F32) return mv_conv_out_act_cl(x, (const float*)pk, bias, y, B, T_, C, ks, pad, act, dtype, stream);
+  dim3 grid(cdiv(T_, 256), B);
+  const size_t lds = (size_t)(256 + ks - 1) * (64 * 2 + 16);
+  if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
+  if (dtype == MV_BF16)
+    hipLaunchKernelGGL((conv_out_dot2_kernel<bf16, 64>), grid, dim3(256), lds, (hipStream_t)stream, (const bf16*)x,
+                       (const uint32_t*)(pk + (size_t)C * ks * 4), bias, (bf16*)y, T_, ks, pad, act);
+  else if (dtype == MV_F16)
+    hipLaunchKernelGGL((conv_out_dot2_kernel<f16, 64>), grid, dim3(256), lds, (hipStream_t)stream, (const f16*)x,
+                       (const uint32_t*)(pk + (size_t)C * ks * 6), bias, (f16*)y, T_, ks, pad, act);
+  else return MV_ERR_DTYPE;
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

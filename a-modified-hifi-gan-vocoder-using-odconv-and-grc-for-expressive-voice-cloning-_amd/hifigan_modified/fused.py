@@ -259,9 +259,9 @@ class GeneratorFused:
         if hit is not None and hit[0] == ver and hit[1].device == device:
             return hit[1], hit[2]
         C, ks = w.shape[1], w.shape[2]
-        wt = torch.empty(ks, C, device=device, dtype=torch.float32)
+        wt = torch.empty(N.lib().mv_conv_out_packed_bytes(C, ks), device=device, dtype=torch.uint8)   # fp32 | bf16 | f16 images
         wd = w.detach().contiguous()
-        N.call("mv_conv_out_pack", c_void_p(wd.data_ptr()), ops._DT[wd.dtype], c_void_p(wt.data_ptr()), C, ks, ops._stream())
+        N.call("mv_conv_out_pack_all", c_void_p(wd.data_ptr()), ops._DT[wd.dtype], c_void_p(wt.data_ptr()), C, ks, ops._stream())
         bias = float(b.detach().float().item())   # host read of one scalar, once per weight version
         self._wt["w"] = (ver, wt, bias)
         return wt, bias
@@ -325,7 +325,7 @@ class GeneratorFused:
         Bx, T, C = x.shape
         k = g.output_proj.kernel_size[0]
         wave = torch.empty(Bx, 1, T, device=mel.device, dtype=dt)
-        N.call("mv_conv_out_act_cl", c_void_p(x.data_ptr()), c_void_p(wt.data_ptr()), bias, c_void_p(wave.data_ptr()),
+        N.call("mv_conv_out_act_packed_cl", c_void_p(x.data_ptr()), c_void_p(wt.data_ptr()), bias, c_void_p(wave.data_ptr()),
                Bx, T, C, k, k // 2, N.ACT_TANH, ops._dt(x), ops._stream())
         if return_stages:
             st = {kk: ops.ntc_to_nct(v) for kk, v in st.items()}   # stages are reported in the public NCT layout

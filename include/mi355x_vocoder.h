@@ -207,6 +207,13 @@ int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const
 int mv_conv_out_pack(const void* w, int param_dtype, float* wt, int C, int ks, void* stream);
 int mv_conv_out_act_cl(const void* x, const float* wt, float bias, void* y, int B, int T, int C, int ks, int pad,
                        int act, int dtype, void* stream);
+/* The same output convolution with all three weight images packed once (fp32 | bf16 | f16, mv_conv_out_packed_bytes): 16-bit storage
+ * runs on the packed dot-product instructions (v_dot2c_f32_bf16 / _f16: two MACs per lane and instruction, fp32 accumulate, weights
+ * in the activation type), fp32 storage on the fp32 image as mv_conv_out_act_cl does. */
+size_t mv_conv_out_packed_bytes(int C, int ks);
+int mv_conv_out_pack_all(const void* w, int param_dtype, void* packed, int C, int ks, void* stream);
+int mv_conv_out_act_packed_cl(const void* x, const void* packed, float bias, void* y, int B, int T, int C, int ks, int pad, int act,
+                              int dtype, void* stream);
 
 /* ================================================================================================
  * Backward / training entry points.  Parameter gradients are always fp32.  Data gradients of the convolutions

@@ -48,7 +48,7 @@ with torch.no_grad():
     wt, bias = fz.out_weights(mel.device)
     wave = torch.empty(B, 1, prev.shape[1], device="cuda", dtype=dt)
     def outc():
-        N.call("mv_conv_out_act_cl", ctypes.c_void_p(prev.data_ptr()), ctypes.c_void_p(wt.data_ptr()), bias,
+        N.call("mv_conv_out_act_packed_cl", ctypes.c_void_p(prev.data_ptr()), ctypes.c_void_p(wt.data_ptr()), bias,
                ctypes.c_void_p(wave.data_ptr()), B, prev.shape[1], 64, 11, 5, N.ACT_TANH, ops._dt(prev), ops._stream())
     t = timeit(outc)
     print(f"out conv+tanh   {t:8.1f} us   {prev.numel() * es / t / 1e3:8.1f} GB/s")
