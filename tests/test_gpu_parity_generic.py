@@ -267,6 +267,11 @@ def test_mrf_fused_vs_generic_and_golden(H, dtype, T, B):
     ("odconvT_k4_s2", (8, 8, 4), dict(stride=2, padding=1)),
     ("odconvT_k8_s4", (24, 16, 8), dict(stride=4, padding=2)),
     ("odconvT_k6_s2", (32, 16, 6), dict(stride=2, padding=2)),
+    # ks = 2*stride with 64 / 128 input channels: the multi-tile kernel (odconv_cl_mt_kernel) in 16-bit storage
+    ("odconvT_c64_k4_s2", (64, 64, 4), dict(stride=2, padding=1)),
+    ("odconvT_c128_k8_s4", (128, 64, 8), dict(stride=4, padding=2)),
+    ("odconvT_c64_k4_s2_op1", (64, 32, 4), dict(stride=2, padding=1, output_padding=1)),
+    ("odconvT_c128_k4_s2", (128, 96, 4), dict(stride=2, padding=1)),
 ])
 @pytest.mark.parametrize("T", [7, 50, 300, 1500])
 def test_odconv_fused_vs_generic(H, name, args, kw, dtype, T):
