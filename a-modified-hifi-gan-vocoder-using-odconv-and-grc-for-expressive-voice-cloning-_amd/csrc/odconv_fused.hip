@@ -591,7 +591,10 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   const size_t xbytes = (size_t)nrows * lds_row_stride(CIN * ES, ES);
   const size_t obytes = (size_t)NB * 16 * (4 * MW * 16 * ES + 16);
   const size_t lds = sizeof(float) * (OD_MAXK + 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
-  if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
+  if (lds > 80 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = odconv_cl_mt_kernel<T, MW, NB, CIN, 4>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   const int ntl = cdiv(p.nq, NB * 16);
   const int gy = cdiv(p.M / 16, 4 * MW);
   // about two workgroups per CU: enough to overlap each other's barriers, few enough to amortise the per-workgroup weight mix
@@ -602,7 +605,7 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   if (TL > 16) TL = 16;
   dim3 grid(cdiv(ntl, TL), gy, p.B);
   if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((odconv_cl_mt_kernel<T, MW, NB, CIN, 4>), grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha,
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha,
                      pooled_in, (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p, TL);
   return MV_OK;
 }
@@ -1005,7 +1008,17 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(2, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else if (wbytes > (1 << 20)) {         // big kernels, medium sequences: 144-column blocks amortise the aggregation
-      OD_GO(1, 2, 9);
+      rc = MV_ERR_UNSUPPORTED;
+      if constexpr (sizeof(T) == 2) {
+        static int mt1 = -1;
+        if (mt1 < 0) { const char* e = getenv("MV_OD_MT1"); mt1 = e ? atoi(e) : 1; }
+        // 256 input channels, ks = 2*stride (ups1): 64-row workgroups keep their 16 mixed fragments per wave resident and walk
+        // the sample's 96-column tiles - the bank fragments are fetched from L2 and mixed once per (sample, row block) instead
+        // of once per tile (37 -> 28.5 us; 144-column tiles without the x look-ahead measured 34 us)
+        if (mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256)
+          rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+      }
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 9);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else {                                 // small kernels, long sequences: HBM-streaming regime
       rc = MV_ERR_UNSUPPORTED;

@@ -272,6 +272,8 @@ def test_mrf_fused_vs_generic_and_golden(H, dtype, T, B):
     ("odconvT_c128_k8_s4", (128, 64, 8), dict(stride=4, padding=2)),
     ("odconvT_c64_k4_s2_op1", (64, 32, 4), dict(stride=2, padding=1, output_padding=1)),
     ("odconvT_c128_k4_s2", (128, 96, 4), dict(stride=2, padding=1)),
+    ("odconvT_c256_k16_s8", (256, 128, 16), dict(stride=8, padding=4)),
+    ("odconvT_c256_k4_s2", (256, 320, 4), dict(stride=2, padding=1)),
 ])
 @pytest.mark.parametrize("T", [7, 50, 300, 1500])
 def test_odconv_fused_vs_generic(H, name, args, kw, dtype, T):
