@@ -442,3 +442,31 @@ def test_long_utterance_takes_the_unfused_prologue(H, Tm):
     assert wave.shape == (1, 1, Tm * 256)
     ref = O.generator_forward(mel, sd, "", spk, emo)
     assert O.rel_l2(wave.cpu(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,ks", [(2, 100, 11), (1, 257, 7), (3, 1000, 11), (2, 5, 3)])
+def test_output_conv_packed_images_vs_fp64(H, dtype, B, T, ks):
+    """mv_conv_out_pack_all + mv_conv_out_act_packed_cl (Conv1d(64, 1, ks, padding=ks//2) + tanh on the channels-last stream): the
+    16-bit images run on v_dot2c_f32_{bf16,f16}, the fp32 image on scalar FMAs; all against fp64 with the weights rounded like the
+    kernel rounds them."""
+    import ctypes
+    from hifigan_modified import ops
+    from hifigan_modified import _native as N
+    torch.manual_seed(ks * 100 + T)
+    C = 64
+    w = torch.randn(1, C, ks, device="cuda") / (C * ks) ** 0.5
+    bias = 0.05
+    x = torch.randn(B, T, C, device="cuda").to(dtype)
+    packed = torch.empty(N.lib().mv_conv_out_packed_bytes(C, ks), device="cuda", dtype=torch.uint8)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    N.call("mv_conv_out_pack_all", P(w), ops._DT[w.dtype], P(packed), C, ks, ops._stream())
+    y = torch.empty(B, 1, T, device="cuda", dtype=dtype)
+    N.call("mv_conv_out_act_packed_cl", P(x), P(packed), bias, P(y), B, T, C, ks, ks // 2, N.ACT_TANH, ops._dt(x), ops._stream())
+    wq = w.to(dtype).double() if dtype != torch.float32 else w.double()
+    ref = torch.tanh(torch.nn.functional.conv1d(x.double().transpose(1, 2), wq, torch.tensor([bias], device="cuda", dtype=torch.float64),
+                                                padding=ks // 2))
+    tol = {torch.float32: 1e-6, torch.float16: 6e-4, torch.bfloat16: 4e-3}[dtype]
+    assert O.rel_l2(y.double().cpu(), ref.cpu()) < tol
+    assert N.lib().mv_conv_out_act_packed_cl(P(x), P(packed), ctypes.c_float(bias), P(y), B, T, 32, ks, ks // 2, N.ACT_TANH, ops._dt(x),
+                                             ops._stream()) == -3        # only the 64-channel stream is built
