@@ -239,7 +239,9 @@ def main():
                 # 37.1 MB written, at this exact workload
                 "traffic": 144_500_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
-                "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic"}
+                "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic; the block also issues 512 MFMAs "
+                        "per 64-step tile (stage 1 is recomputed in every pass, tap/row padding included) = 27 us of matrix-pipe time at "
+                        "B=32 x 8192, so about half of the block time is MFMA issue, not memory"}
 
     # per-kernel HBM figures of the HBM-bound fused ODConvTranspose1d launches ((Cin/f + Cout) * 2 B per output sample)
     od_roof = None
