@@ -235,9 +235,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "mv::mrf_kernel (fused MRF block = 3 pass launches)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 # HBM bytes per block from the PMC passes committed in profiles/r01_pmc_traffic_bf16.csv (separate --pmc FETCH_SIZE /
-                # WRITE_SIZE runs of this command, FETCH_SIZE doubled per the gfx950 correction): 34.3 + 34.6 + 38.5 MB read,
-                # 37.1 MB written, at this exact workload
-                "traffic": 144_500_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
+                # WRITE_SIZE runs of this command, FETCH_SIZE doubled per the gfx950 correction): 34.3 + 34.6 + 35.3 MB read,
+                # 34.0 MB written, at this exact workload
+                "traffic": 138_200_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
                 "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
                 "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic; the block also issues 512 MFMAs "
                         "per 64-step tile (stage 1 is recomputed in every pass, tap/row padding included) = 27 us of matrix-pipe time at "
