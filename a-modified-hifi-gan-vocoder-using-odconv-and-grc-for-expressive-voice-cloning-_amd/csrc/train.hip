@@ -4,6 +4,7 @@
 //   AdamW:    conditioned_hifigan.py:219 (torch.optim.AdamW semantics: decoupled weight decay, bias correction)
 //   mel loss: defined by this build (the reference only has placeholders)
 #include "common.h"
+#include <cstdlib>
 
 namespace mv {
 
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(256) void multi_gather_kernel(const GatherDesc* __r
 }
 
 // ------------------------------------------------------------------------------------------- log-mel spectrogram loss
-// frames: reflect-pad (n_fft-hop)/2, hop, periodic Hann; |rDFT| (direct O(N^2) DFT with an exact (k*n mod N) twiddle table
-// in LDS), mel = fb @ mag, logmel = log(max(mel, clamp)); loss = weight * mean |logmel - target|.
+// frames: reflect-pad (n_fft-hop)/2, hop, periodic Hann; |rFFT| (power-of-two n_fft: radix-2 FFT of the frame in LDS, forward and
+// adjoint; otherwise a direct O(N^2) DFT with an exact (k*n mod N) twiddle table), mel = fb @ mag, logmel = log(max(mel, clamp)); loss = weight * mean |logmel - target|.
 // One workgroup per (b, frame).  Backward recomputes the frame spectrum and scatters d wave with atomics (frames overlap 4x).
 __device__ __forceinline__ int reflect_idx(int i, int Tn) {
   if (i < 0) i = -i;
@@ -195,20 +196,42 @@ __device__ __forceinline__ int reflect_idx(int i, int Tn) {
   return i;
 }
 
+// In-LDS radix-2 FFT of N = 2^logn complex points (decimation in time; the caller stored its input in bit-reversed order).
+// sgn = -1: forward transform e^{-2 pi i kn/N}; +1: the adjoint.  Twiddles come from the shared cos/sin tables (index j*N/m),
+// N/2 butterflies per stage spread over the workgroup, one barrier per stage.
+__device__ __forceinline__ void lds_fft(float* xr, float* xi, const float* ct, const float* stb, int logn, float sgn) {
+  const int N = 1 << logn;
+  for (int s = 1; s <= logn; ++s) {
+    const int half = 1 << (s - 1), tws = N >> s;
+    for (int j = threadIdx.x; j < N / 2; j += blockDim.x) {
+      const int pos = j & (half - 1), i0 = ((j >> (s - 1)) << s) + pos, i1 = i0 + half;
+      const float wr = ct[pos * tws], wi = sgn * stb[pos * tws];
+      const float ar = xr[i1], ai = xi[i1];
+      const float tr = wr * ar - wi * ai, ti = wr * ai + wi * ar;
+      const float br = xr[i0], bi = xi[i0];
+      xr[i1] = br - tr; xi[i1] = bi - ti;
+      xr[i0] = br + tr; xi[i0] = bi + ti;
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wave, const float* __restrict__ fb,
                                                        const float* __restrict__ target, float* __restrict__ mel_out,
                                                        float* __restrict__ loss_acc, float* __restrict__ gwave,
                                                        int Tn, int n_fft, int hop, int n_mels, int n_frames, float clampv,
-                                                       float weight, long n_total, int kind) {
+                                                       float weight, long n_total, int kind, int logn) {
   extern __shared__ float sm[];
   const int nb = n_fft / 2 + 1;
+  // logn > 0 (n_fft a power of two): rFFT path - re / im hold all n_fft points of the in-LDS FFT, `scr` the adjoint's imaginary part
   float* fr = sm;                 // [n_fft] windowed frame
   float* ct = fr + n_fft;         // [n_fft] cos table
   float* stb = ct + n_fft;        // [n_fft] sin table
-  float* re = stb + n_fft;        // [nb]
-  float* im = re + nb;            // [nb]
-  float* mag = im + nb;           // [nb]  (bwd: reused for g_mag)
+  float* re = stb + n_fft;        // [nb], FFT: [n_fft]
+  float* im = re + (logn > 0 ? n_fft : nb);
+  float* scr = im + (logn > 0 ? n_fft : nb);   // FFT: [n_fft]
+  float* mag = scr + (logn > 0 ? n_fft : 0);   // [nb]
   float* gml = mag + nb;          // [n_mels] dL/dmel
   float* red = gml + n_mels;      // [32]
   const int b = blockIdx.y, f = blockIdx.x, tid = threadIdx.x;
@@ -222,16 +245,26 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wav
     stb[n] = sinf(w0 * n);
   }
   __syncthreads();
-  for (int k = tid; k < nb; k += blockDim.x) {
-    float a = 0.f, c = 0.f;
-    int idx = 0;
-    for (int n = 0; n < n_fft; ++n) {
-      a += fr[n] * ct[idx];
-      c -= fr[n] * stb[idx];
-      idx += k; if (idx >= n_fft) idx -= n_fft;
+  if (logn > 0) {
+    for (int n = tid; n < n_fft; n += blockDim.x) {
+      const int r = (int)(__brev((unsigned)n) >> (32 - logn));
+      re[r] = fr[n]; im[r] = 0.f;
     }
-    re[k] = a; im[k] = c;
-    mag[k] = sqrtf(a * a + c * c + 1e-9f);
+    __syncthreads();
+    lds_fft(re, im, ct, stb, logn, -1.f);
+    for (int k = tid; k < nb; k += blockDim.x) mag[k] = sqrtf(re[k] * re[k] + im[k] * im[k] + 1e-9f);
+  } else {
+    for (int k = tid; k < nb; k += blockDim.x) {
+      float a = 0.f, c = 0.f;
+      int idx = 0;
+      for (int n = 0; n < n_fft; ++n) {
+        a += fr[n] * ct[idx];
+        c -= fr[n] * stb[idx];
+        idx += k; if (idx >= n_fft) idx -= n_fft;
+      }
+      re[k] = a; im[k] = c;
+      mag[k] = sqrtf(a * a + c * c + 1e-9f);
+    }
   }
   __syncthreads();
   float lsum = 0.f;
@@ -263,12 +296,24 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const T* __restrict__ wav
   }
   __syncthreads();
   // g_frame[n] = sum_k g_re cos(2 pi k n/N) - g_im sin(2 pi k n/N) ; d wave += g_frame * win
+  if (logn > 0) {
+    // = Re( sum_{k < nb} (g_re + i g_im) e^{+2 pi i kn/N} ): the adjoint FFT of the half spectrum, zero above Nyquist
+    for (int k = tid; k < n_fft; k += blockDim.x) {
+      const int r = (int)(__brev((unsigned)k) >> (32 - logn));
+      fr[r] = k < nb ? re[k] : 0.f; scr[r] = k < nb ? im[k] : 0.f;
+    }
+    __syncthreads();
+    lds_fft(fr, scr, ct, stb, logn, 1.f);
+  }
   for (int n = tid; n < n_fft; n += blockDim.x) {
     float a = 0.f;
-    int idx = 0;
-    for (int k = 0; k < nb; ++k) {
-      a += re[k] * ct[idx] - im[k] * stb[idx];
-      idx += n; if (idx >= n_fft) idx -= n_fft;
+    if (logn > 0) a = fr[n];
+    else {
+      int idx = 0;
+      for (int k = 0; k < nb; ++k) {
+        a += re[k] * ct[idx] - im[k] * stb[idx];
+        idx += n; if (idx >= n_fft) idx -= n_fft;
+      }
     }
     const float win = 0.5f - 0.5f * ct[n];
     const int ti = reflect_idx(f * hop - padn + n, Tn);
@@ -365,7 +410,13 @@ extern "C" int mv_mel_loss(const void* wave, const float* fb, const float* targe
   MV_CHECK_ARG(kind == 0 || kind == 1);
   MV_CHECK_ARG((n_fft - hop) / 2 < T_);
   const int n_frames = T_ / hop, nb = n_fft / 2 + 1;
-  const size_t lds = sizeof(float) * (3 * (size_t)n_fft + 3 * (size_t)nb + n_mels + 32);
+  int logn = 0;                                       // rFFT path for power-of-two n_fft (env MV_MEL_DFT=1: the direct DFT, for comparison)
+  {
+    static int force_dft = -1;
+    if (force_dft < 0) { const char* e = getenv("MV_MEL_DFT"); force_dft = e ? atoi(e) : 0; }
+    if (!force_dft && n_fft >= 32 && (n_fft & (n_fft - 1)) == 0) while ((1 << logn) < n_fft) ++logn;
+  }
+  const size_t lds = sizeof(float) * ((logn > 0 ? 6 * (size_t)n_fft + nb : 3 * (size_t)n_fft + 3 * (size_t)nb) + n_mels + 32);
   if (lds > 160 * 1024 || B > 65535) return MV_ERR_UNSUPPORTED;
   const long n_total = (long)B * n_mels * n_frames;
   dim3 grid(n_frames, B);
@@ -374,12 +425,12 @@ extern "C" int mv_mel_loss(const void* wave, const float* fb, const float* targe
       auto kern = mel_loss_kernel<T, true>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, target, mel_out,
-                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
+                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind, logn);
     } else {
       auto kern = mel_loss_kernel<T, false>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, (const T*)wave, fb, target, mel_out,
-                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind);
+                         loss_acc, gwave, T_, n_fft, hop, n_mels, n_frames, clampv, weight, n_total, kind, logn);
     }
   });
   MV_LAUNCH_CHECK();

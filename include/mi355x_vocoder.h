@@ -283,7 +283,7 @@ int mv_scale(void* x, const float* factor_dev, float factor, long n, int dtype, 
 
 /* Log-mel spectrogram (+ L1 loss against `target`, fp32 [B][n_mels][T/hop]) of wave [B][1][T]; defined by this build (the
  * reference has only placeholders: complete_vocoder.py:210-212, conditioned_hifigan.py:269-274).  Frames: reflect pad
- * (n_fft-hop)/2, periodic Hann, |rDFT|, mel = fb [n_mels][n_fft/2+1] (fp32) @ mag, log(max(., clamp)).
+ * (n_fft-hop)/2, periodic Hann, |rFFT| (in-LDS radix-2 FFT when n_fft is a power of two, direct DFT otherwise), mel = fb [n_mels][n_fft/2+1] (fp32) @ mag, log(max(., clamp)).
  *   mel_out (optional fp32 [B][n_mels][T/hop]); loss_acc += weight * mean|logmel - target| (kind 0) or weight * mean (logmel - target)^2 (kind 1);
  *   backward != 0: gwave (fp32 [B][T], zero on entry) += d loss / d wave. */
 int mv_mel_loss(const void* wave, const float* fb, const float* target, float* mel_out, float* loss_acc, float* gwave,

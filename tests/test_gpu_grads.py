@@ -437,3 +437,29 @@ def test_dropout_mask_follows_torch_manual_seed(H):
     torch.manual_seed(7); a2 = F_.dropout_mask((4, 64, 100), 0.1, "cuda")
     assert torch.equal(a, a2) and not torch.equal(a, b)
     assert abs(a.float().mean().item() - 0.9) < 0.02
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels,sr,T", [(1024, 256, 80, 22050, 4096), (2048, 512, 128, 48000, 8192), (64, 16, 20, 22050, 256),
+                                                   (960, 240, 80, 22050, 1920), (48, 16, 10, 16000, 160)])
+@pytest.mark.parametrize("kind", ["l1", "mse"])
+def test_mel_loss_fft_and_dft_paths_vs_oracle(H, n_fft, hop, n_mels, sr, T, kind):
+    """Power-of-two n_fft runs the in-LDS radix-2 rFFT (forward and adjoint), anything else the direct DFT: both against the oracle's
+    explicit-DFT definition in fp64, value and d loss / d wave."""
+    from hifigan_modified import functional as Fn
+    from hifigan_modified.mel import mel_filterbank
+    torch.manual_seed(n_fft + T)
+    wave = (torch.randn(2, 1, T) * 0.3).clamp(-1, 1)
+    target = torch.randn(2, n_mels, T // hop)
+    kw = dict(sr=sr, n_fft=n_fft, hop=hop, n_mels=n_mels, fmax=sr / 2)
+    w_ref = wave.clone().double().requires_grad_(True)
+    d = O.mel_spectrogram(w_ref, **kw) - target.double()
+    ref = d.abs().mean() if kind == "l1" else (d * d).mean()
+    ref.backward()
+    fb = mel_filterbank(sr, n_fft, n_mels, 0.0, sr / 2, device="cuda")
+    w = wave.cuda().requires_grad_(True)
+    loss = (Fn.mel_l1 if kind == "l1" else Fn.mel_mse)(w, target.cuda(), fb, n_fft=n_fft, hop=hop)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref))
+    assert O.rel_l2(w.grad.cpu(), w_ref.grad.float()) < 2e-3
+    mel = Fn.mel_spectrogram(wave.cuda(), fb, n_fft=n_fft, hop=hop)
+    assert O.rel_l2(mel.cpu(), O.mel_spectrogram(wave.double(), **kw).float()) < 1e-4
