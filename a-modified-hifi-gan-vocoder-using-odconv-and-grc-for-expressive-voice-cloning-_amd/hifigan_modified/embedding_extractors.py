@@ -145,8 +145,8 @@ class SE_Module(nn.Module):
         m = _mean_t(x_cl)
         g = _f32(B, C, device=x_cl.device)
         f0, f2 = self.fc[0], self.fc[2]
-        N.call("mv_se_gate", ops._p(m), ops._p(f0.weight.detach()), ops._p(f0.bias.detach()), ops._p(f2.weight.detach()),
-               ops._p(f2.bias.detach()), ops._p(g), B, C, f0.weight.shape[0], ops._stream())
+        w1, b1, w2, b2 = (t.detach().float().contiguous() for t in (f0.weight, f0.bias, f2.weight, f2.bias))   # no-ops for fp32 masters
+        N.call("mv_se_gate", ops._p(m), ops._p(w1), ops._p(b1), ops._p(w2), ops._p(b2), ops._p(g), B, C, w1.shape[0], ops._stream())
         return g
 
     def scale_add_cl(self, x_cl, res_cl):

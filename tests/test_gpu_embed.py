@@ -261,3 +261,16 @@ def test_extractor_edge_shapes(H, dtype):
         assert rel_l2(e.float().cpu(), E.ecapa_tdnn(x, sd)) < 3 * TOL[dtype], (B, T)
     with pytest.raises(RuntimeError):
         spk_m(torch.randn(2, 80, device="cuda"))               # not [B, C, T]
+
+
+def test_extractor_with_16bit_parameters_matches_fp32_masters(H):
+    """`module.half()` (parameters stored in fp16) must give the embeddings of the fp32-master module on the same fp16 input: every
+    kernel that takes fp32 weights gets a converted copy, never the raw 16-bit storage."""
+    m = build("extractor", None).cuda()
+    torch.manual_seed(11)
+    x = torch.randn(2, 80, 40, device="cuda").half()
+    spk, emo = m(x)
+    import copy
+    mh = copy.deepcopy(m).half()
+    spk_h, emo_h = mh(x)
+    assert rel_l2(spk_h.float().cpu(), spk.float().cpu()) < 3e-3 and rel_l2(emo_h.float().cpu(), emo.float().cpu()) < 6e-3
