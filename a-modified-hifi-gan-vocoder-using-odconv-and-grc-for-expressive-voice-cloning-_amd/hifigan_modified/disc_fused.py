@@ -30,7 +30,7 @@ class _PackCache:
 
     def _lookup(self, param, kind):
         key = (id(param), kind)
-        ver = (param._version, ops.param_epoch(), param.data_ptr())
+        ver = (param._version, ops.param_epoch_of(param), param.data_ptr())
         hit = self.d.get(key)
         if hit is not None and hit[0]() is param and hit[1] == ver:
             return key, ver, hit[2]

@@ -57,10 +57,19 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 _EPOCH = [0]
 
 
-def bump_param_epoch():
-    """Called by optimizers that update parameters in place behind torch's back (flat-arena AdamW): invalidates
-    every cached cast / packed weight."""
+_FINE = [0]             # bumps that are not attributed to one flat-arena optimizer (broadcast, load)
+
+
+def bump_param_epoch(owner=None):
+    """Called by code that updates parameters in place behind torch's back (flat-arena AdamW, broadcast): invalidates cached
+    casts / packed weights.  `owner` (a flat-arena optimizer): only ITS parameters changed - caches that ask `param_epoch_of`
+    keep the other optimizer's entries (the discriminator packs survive the generator's step and vice versa); `param_epoch()`
+    still moves on every bump for the coarse caches."""
     _EPOCH[0] += 1
+    if owner is None:
+        _FINE[0] += 1
+    else:
+        owner._epoch = getattr(owner, "_epoch", 0) + 1
 
 
 def param_epoch():
@@ -68,6 +77,15 @@ def param_epoch():
 
 
 _SHADOW_OWNERS = {}     # id(parameter) -> weakref(flat-arena optimizer holding a 16-bit shadow of it)
+
+
+def param_epoch_of(p):
+    """Epoch of ONE parameter: (unattributed bumps, its flat-arena owner's own counter)."""
+    ref = _SHADOW_OWNERS.get(id(p))
+    opt = ref() if ref is not None else None
+    if opt is not None and opt.owns(p):
+        return (_FINE[0], getattr(opt, "_epoch", 0))
+    return (_FINE[0], _EPOCH[0])     # no (live) owner: any bump may have touched it
 
 
 def register_shadow_owner(opt, params):

@@ -85,13 +85,20 @@ class FlatAdamW:
                c_void_p(self.exp_avg.data_ptr()), c_void_p(self.exp_avg_sq.data_ptr()), self.numel, float(self.lr),
                float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
                int(self.step_count), float(grad_scale), ops._stream())
-        ops.bump_param_epoch()           # in-place arena update: cached casts / packed weights must refresh
+        ops.bump_param_epoch(self)       # in-place arena update: cached casts / packed weights of THESE parameters must refresh
         self._refresh_shadows()
 
     def _refresh_shadows(self):
         for dt, sh in self._shadows.items():
             N.call("mv_cast", c_void_p(self.flat_p.data_ptr()), N.MV_F32, c_void_p(sh.data_ptr()), ops._DT[dt], self.numel, ops._stream())
-        self._shadow_state = (ops.param_epoch(), [p._version for p in self.params])
+        self._shadow_state = (self._state_epoch(), [p._version for p in self.params])
+
+    def _state_epoch(self):
+        return (ops._FINE[0], getattr(self, "_epoch", 0))
+
+    def owns(self, p):
+        i = self._index.get(id(p))
+        return i is not None and self.params[i] is p
 
     def shadow_view(self, p, dtype):
         """The `dtype` copy of parameter p as a view of the arena's shadow, or None when p was modified behind the arena's back
@@ -100,8 +107,8 @@ class FlatAdamW:
         if i is None or self.params[i] is not p:
             return None
         st = self._shadow_state
-        if dtype not in self._shadows or st is None or st[0] != ops.param_epoch() or st[1][i] != p._version:
-            if st is not None and st[0] == ops.param_epoch() and st[1][i] != p._version:
+        if dtype not in self._shadows or st is None or st[0] != self._state_epoch() or st[1][i] != p._version:
+            if st is not None and st[0] == self._state_epoch() and st[1][i] != p._version:
                 return None
             if dtype not in self._shadows:
                 self._shadows[dtype] = torch.empty(self.numel, device=self.flat_p.device, dtype=dtype)

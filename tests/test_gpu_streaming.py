@@ -195,3 +195,44 @@ def test_hifigan_trainer_variant_a_steps_and_checkpoints(H, tmp_path, dtype):
     tr.save_checkpoint(path, epoch=3, loss=total)
     ck = torch.load(path, map_location="cpu", weights_only=True)
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"} and ck["epoch"] == 3
+
+
+def test_pack_cache_follows_each_optimizer_separately():
+    """Flat-arena AdamW updates weights behind torch's back: the discriminator's packed MFMA weights must be rebuilt after ITS step,
+    survive the generator optimizer's step untouched, and always equal a from-scratch pack."""
+    import hifigan_modified as H
+    from hifigan_modified import disc_fused
+    torch.manual_seed(0)
+    voc = H.ModifiedHiFiGANVocoder(hidden_channels=64)
+    tr = H.VocoderTrainer(voc, device=torch.device("cuda"))
+    torch.manual_seed(1)
+    mel = torch.randn(2, 80, 8, device="cuda").bfloat16()
+    real = torch.randn(2, 1, 2048, device="cuda").clamp(-1, 1).bfloat16()
+    spk, emo = torch.randn(2, 192, device="cuda").bfloat16(), torch.randn(2, 256, device="cuda").bfloat16()
+    probe = torch.randn(2, 1, 2048, device="cuda").clamp(-1, 1).bfloat16()
+
+    def d_out():
+        with torch.no_grad():
+            return torch.cat([o.float().flatten() for o in voc.discriminators.mpd(probe) + voc.discriminators.msd(probe)])
+
+    def fresh():
+        saved = disc_fused._packs.d
+        disc_fused._packs.d = {}
+        try:
+            return d_out()
+        finally:
+            disc_fused._packs.d = saved
+
+    y0 = d_out()
+    tr.train_step(mel, real, spk, emo)                     # D step then G step
+    y1 = d_out()
+    assert not torch.equal(y0, y1)                         # the D update is visible through the cache
+    assert torch.equal(y1, fresh())                        # and equals a from-scratch pack
+    n_entries = len(disc_fused._packs.d)
+    tr.generator_optimizer.zero_grad()
+    tr.generator_optimizer.step()                          # G-only update (zero grads: weight decay still moves G)
+    assert torch.equal(d_out(), y1) and len(disc_fused._packs.d) == n_entries
+    tr.discriminator_optimizer.zero_grad()
+    tr.discriminator_optimizer.step()                      # D-only update (weight decay)
+    y2 = d_out()
+    assert not torch.equal(y2, y1) and torch.equal(y2, fresh())
