@@ -1248,8 +1248,13 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
   if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;   // 16-bit storage only (transposed LDS reads); callers fall back to the generic kernel
   hipStream_t s = (hipStream_t)stream;
-  MV_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)Cout * Cin * kh * kw, s));
-  if (gb) MV_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Cout, s));
+  const size_t wn = (size_t)Cout * Cin * kh * kw;
+  if (gb && gb == workspace + wn) {                  // bias sums placed right behind the workspace: one fill instead of two
+    MV_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (wn + Cout), s));
+  } else {
+    MV_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * wn, s));
+    if (gb) MV_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Cout, s));
+  }
   int rc = MV_ERR_UNSUPPORTED;
   if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, gb, B, H, W, Cin, Cout, kh, kw, dil_w, s);
   else if (dtype == MV_F16) rc = dwgrad_dispatch<f16>(x, g, workspace, gb, B, H, W, Cin, Cout, kh, kw, dil_w, s);

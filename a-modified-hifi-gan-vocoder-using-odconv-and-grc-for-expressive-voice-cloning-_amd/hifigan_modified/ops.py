@@ -376,8 +376,9 @@ def dconv_wgrad_cl(x_cl, g_cl, kh, kw, dil=1, want_bias=False):
     B, H, W, Cin = (shp[0], 1, shp[1], shp[2]) if x_cl.dim() == 3 else shp
     Cout = g_cl.shape[-1]
     gw = _f32(Cout, Cin, kh, kw, device=x_cl.device)
-    gb = _f32(Cout, device=x_cl.device) if want_bias else None
-    ws = _f32(kh * kw, Cout, Cin, device=x_cl.device)
+    wn = kh * kw * Cout * Cin
+    ws = _f32(wn + (Cout if want_bias else 0), device=x_cl.device)     # tap-major workspace | bias sums: zeroed by ONE fill in the entry
+    gb = ws[wn:] if want_bias else None
     N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(gb), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
     return (gw, gb) if want_bias else gw
 
