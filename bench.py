@@ -29,7 +29,7 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None):
+def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None, check48=None):
     """The CPU leg - the only place bench.py touches oracle/ (as the checker and the reported baseline, never as the thing
     measured).  `checks`: {name: (gpu waveform on the host, (mel, spk, emo) fp32 host inputs)} -> rel-L2 of each against the
     oracle, returned under "parity".
@@ -74,6 +74,11 @@ def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None):
         with torch.no_grad():
             for name, (wave, (m, sp, em)) in checks.items():
                 out["parity"][name] = O.rel_l2(wave, O.generator_forward(m, sd, "", sp, em))
+    if check48 is not None:          # 48 kHz leg: one B=2 oracle forward as its checker
+        w48, (mm, ss, ee), sd48 = check48
+        torch.set_num_threads(best["cores"])
+        with torch.no_grad():
+            out.setdefault("parity", {})["config_48k_fp16"] = O.rel_l2(w48, O.generator_forward(mm, sd48, "", ss, ee, upsample_factors=(8, 8, 4, 2)))
     if embed_check is not None:      # conditioning producers: oracle/embed_oracle.py as checker and as the CPU figure (bounded: <= 3 s)
         from oracle import embed_oracle as E
         esd, emel, spk_gpu, emo_gpu = embed_check
@@ -136,6 +141,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conditioning", action="store_true", help="skip the embedding-extractor leg")
+    ap.add_argument("--no-48k", action="store_true", help="skip the 48 kHz fp16 leg (BASELINE configs[4] shapes)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
     ap.add_argument("--train-warmup", type=int, default=2)
@@ -310,6 +316,34 @@ def main():
                                             "parity_rel_l2_vs_oracle": None}
             del gv16, g16
 
+    # ---------------------------------------------------------------- BASELINE configs[4]: 48 kHz variant, fp16, single-GPU share
+    # 128-mel, upsample [8,8,4,2] (hop 512), 16 mel frames -> 8192 samples, B=32 per GPU: same kernels, other shapes (ups2 = k8 s4).
+    cfg48 = None
+    if rank == 0 and world == 1 and not args.eager and not args.no_48k:
+        from hifigan_modified.graphs import GraphedVocoder
+        torch.manual_seed(0)
+        g48 = H.ModifiedHiFiGANGenerator(mel_channels=128, upsample_factors=[8, 8, 4, 2])
+        sd48 = {k: v.detach().clone() for k, v in g48.state_dict().items()}
+        g48 = g48.to(dev).half().train(False)
+        torch.manual_seed(1)
+        m48 = torch.randn(B, 128, 16, device=dev).half()
+        with torch.no_grad():
+            checks48 = (g48(m48[:2], spk[:2].half(), emo[:2].half()).float().cpu(), (m48[:2].float().cpu(), spk[:2].float().cpu(), emo[:2].float().cpu()), sd48)
+        gv48 = GraphedVocoder(g48, m48, spk.half(), emo.half())
+        for _ in range(20):
+            gv48.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n48 = 200
+        for _ in range(n48):
+            gv48.replay()
+        torch.cuda.synchronize()
+        el48 = time.perf_counter() - t1
+        cfg48 = {"workload": "configs[4] per-GPU share: 128-mel 48 kHz generator, upsample [8,8,4,2], B=%d x 16 mel frames -> 8192 samples, fp16" % B,
+                 "value": round(B * 16 * n48 / el48, 1), "unit": "mel-frames/s", "samples_per_s": round(B * 8192 * n48 / el48, 1),
+                 "ms_per_step": round(el48 / n48 * 1e3, 4), "dtype": "fp16", "launch": "hipgraph", "parity_rel_l2_vs_oracle": None}
+        del gv48, g48
+
     # ---------------------------------------------------------------- conditioning producers
     # ECAPA-TDNN + Emotion2Vec on the same mel batch (what ModifiedHiFiGANVocoder.forward(extract_embeddings=True) runs in front
     # of the generator): throughput of the captured forward, the dominant kernel's roofline, parity against the CPU oracle.
@@ -435,10 +469,14 @@ def main():
             "parity_grade": parity_grade,
             "train": train,
             "conditioning": conditioning,
+            "config_48k_fp16": cfg48,
         }
         if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks, embed_check=embed_check)
+            cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks, embed_check=embed_check,
+                              check48=checks48 if cfg48 is not None else None)
             par = cb.pop("parity", {})
+            if cfg48 is not None:
+                cfg48["parity_rel_l2_vs_oracle"] = par.get("config_48k_fp16")
             if conditioning is not None:
                 conditioning["parity_rel_l2_vs_oracle"] = par.get("conditioning")
                 conditioning["cpu_baseline"] = cb.pop("conditioning", None)
