@@ -29,7 +29,7 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None, check48=None):
+def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None, check48=None, check_v3=None):
     """The CPU leg - the only place bench.py touches oracle/ (as the checker and the reported baseline, never as the thing
     measured).  `checks`: {name: (gpu waveform on the host, (mel, spk, emo) fp32 host inputs)} -> rel-L2 of each against the
     oracle, returned under "parity".
@@ -74,6 +74,18 @@ def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None, ch
         with torch.no_grad():
             for name, (wave, (m, sp, em)) in checks.items():
                 out["parity"][name] = O.rel_l2(wave, O.generator_forward(m, sd, "", sp, em))
+    if check_v3 is not None:         # configs[0]: the plain V3 generator on the CPU (restatement of the published architecture), B=1
+        w3, m3, sd3 = check_v3
+        torch.set_num_threads(best["cores"])
+        with torch.no_grad():
+            ref3 = O.plain_hifigan_forward(m3, sd3)
+            out.setdefault("parity", {})["config_v3_plain"] = O.rel_l2(w3, ref3)
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 2.0 and n < 10:
+                O.plain_hifigan_forward(m3, sd3)
+                n += 1
+            out["config_v3_plain"] = {"value": round(344 * n / (time.perf_counter() - t0), 1), "unit": "mel-frames/s", "cores": best["cores"],
+                                      "kind": "port", "sample": "%d forwards of B=1 x 344 frames, fp32" % n}
     if check48 is not None:          # 48 kHz leg: one B=2 oracle forward as its checker
         w48, (mm, ss, ee), sd48 = check48
         torch.set_num_threads(best["cores"])
@@ -141,6 +153,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conditioning", action="store_true", help="skip the embedding-extractor leg")
+    ap.add_argument("--no-v3", action="store_true", help="skip the plain HiFi-GAN V3 leg (BASELINE configs[0])")
     ap.add_argument("--no-48k", action="store_true", help="skip the 48 kHz fp16 leg (BASELINE configs[4] shapes)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
@@ -344,6 +357,34 @@ def main():
                  "ms_per_step": round(el48 / n48 * 1e3, 4), "dtype": "fp16", "launch": "hipgraph", "parity_rel_l2_vs_oracle": None}
         del gv48, g48
 
+    # ---------------------------------------------------------------- BASELINE configs[0]: plain HiFi-GAN V3 (no ODConv), batch 1
+    # the reference's own CPU-runnable case (fairseq's generator: parity unpinned); GPU figure + the CPU restatement timed
+    cfg_v3, check_v3 = None, None
+    if rank == 0 and world == 1 and not args.no_v3:
+        from hifigan_modified.plain_hifigan import PlainHiFiGANGenerator
+        torch.manual_seed(0)
+        v3 = PlainHiFiGANGenerator()
+        sd_v3 = {k: v.detach().clone() for k, v in v3.state_dict().items()}
+        v3 = v3.to(dev).train(False)
+        torch.manual_seed(1)
+        mel_v3 = torch.randn(1, 80, 344, device=dev)
+        with torch.no_grad():
+            w_v3 = v3(mel_v3)
+            for _ in range(3):
+                v3(mel_v3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_v3 = 20
+            for _ in range(n_v3):
+                v3(mel_v3)
+            torch.cuda.synchronize()
+            el_v3 = time.perf_counter() - t1
+        check_v3 = (w_v3.cpu(), mel_v3.cpu(), sd_v3)
+        cfg_v3 = {"workload": "configs[0]: plain HiFi-GAN V3 generator, B=1 x 344 mel frames (4 s at 22.05 kHz), fp32, generic HIP kernels, eager",
+                  "value": round(344 * n_v3 / el_v3, 1), "unit": "mel-frames/s", "ms_per_step": round(el_v3 / n_v3 * 1e3, 3), "dtype": "fp32",
+                  "parity_rel_l2_vs_cpu_restatement": None, "cpu": None, "note": "parity unpinned: fairseq generator absent from the reference tree"}
+        del v3
+
     # ---------------------------------------------------------------- conditioning producers
     # ECAPA-TDNN + Emotion2Vec on the same mel batch (what ModifiedHiFiGANVocoder.forward(extract_embeddings=True) runs in front
     # of the generator): throughput of the captured forward, the dominant kernel's roofline, parity against the CPU oracle.
@@ -470,13 +511,17 @@ def main():
             "train": train,
             "conditioning": conditioning,
             "config_48k_fp16": cfg48,
+            "config_v3_plain": cfg_v3,
         }
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks, embed_check=embed_check,
-                              check48=checks48 if cfg48 is not None else None)
+                              check48=checks48 if cfg48 is not None else None, check_v3=check_v3)
             par = cb.pop("parity", {})
             if cfg48 is not None:
                 cfg48["parity_rel_l2_vs_oracle"] = par.get("config_48k_fp16")
+            if cfg_v3 is not None:
+                cfg_v3["parity_rel_l2_vs_cpu_restatement"] = par.get("config_v3_plain")
+                cfg_v3["cpu"] = cb.pop("config_v3_plain", None)
             if conditioning is not None:
                 conditioning["parity_rel_l2_vs_oracle"] = par.get("conditioning")
                 conditioning["cpu_baseline"] = cb.pop("conditioning", None)
