@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void scale_kernel(T* __restrict__ x, const flo
     st<T>(x + i, ld<T>(x + i) * f);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void scale_to_kernel(const T* __restrict__ x, T* __restrict__ y, const float* __restrict__ factor_dev,
+                                                       float factor, long n) {
+  const float f = factor_dev ? factor * factor_dev[0] : factor;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    st<T>(y + i, ld<T>(x + i) * f);
+}
+
 // ------------------------------------------------------------------------------------------- AdamW on a flat fp32 arena
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
@@ -378,6 +386,14 @@ extern "C" int mv_loss_fwd_bwd(const void* x, const void* y, float c, float weig
 extern "C" int mv_scale(void* x, const float* factor_dev, float factor, long n, int dtype, void* stream) {
   MV_CHECK_ARG(x && n > 0);
   MV_DISPATCH(dtype, hipLaunchKernelGGL(scale_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (T*)x,
+                                        factor_dev, factor, n));
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_scale_to(const void* x, void* y, const float* factor_dev, float factor, long n, int dtype, void* stream) {
+  MV_CHECK_ARG(x && y && n > 0);
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(scale_to_kernel<T>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y,
                                         factor_dev, factor, n));
   MV_LAUNCH_CHECK();
   return MV_OK;

@@ -683,9 +683,9 @@ class _Loss(Function):
     def backward(ctx, g):
         gx, gyt = ctx.saved_tensors
         gdev = g.reshape(1).float()
-        gx = ops.scale_(gx.clone(), 1.0, gdev)
+        gx = ops.scale_to(gx, 1.0, gdev)
         if gyt is not None:
-            gyt = ops.scale_(gyt.clone(), 1.0, gdev)
+            gyt = ops.scale_to(gyt, 1.0, gdev)
         return gx, gyt, None, None, None
 
 
@@ -726,7 +726,7 @@ class _MelL1(Function):
     @staticmethod
     def backward(ctx, g):
         (gwave,) = ctx.saved_tensors
-        gw = ops.scale_(gwave.clone(), 1.0, g.reshape(1).float())
+        gw = ops.scale_to(gwave, 1.0, g.reshape(1).float())
         return (gw if ctx.dtype == torch.float32 else ops.cast(gw, ctx.dtype)), None, None, None, None, None, None, None
 
 

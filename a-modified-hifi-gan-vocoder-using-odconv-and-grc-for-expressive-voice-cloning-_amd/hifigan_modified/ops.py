@@ -528,6 +528,14 @@ def loss_fwd_bwd(x, y, kind, c=0.0, weight=1.0, want_gx=True, want_gy=False, acc
     return acc, gx, gyt
 
 
+def scale_to(x, factor=1.0, factor_dev=None):
+    """x * factor * factor_dev[0] into a new tensor (one launch; x is left untouched)."""
+    x = _c(x)
+    y = torch.empty_like(x)
+    N.call("mv_scale_to", _p(x), _p(y), _p(factor_dev), float(factor), x.numel(), _dt(x), _stream())
+    return y
+
+
 def scale_(x, factor=1.0, factor_dev=None):
     assert x.is_contiguous()
     N.call("mv_scale", _p(x), _p(factor_dev), float(factor), x.numel(), _dt(x), _stream())

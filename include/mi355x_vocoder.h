@@ -280,6 +280,8 @@ int mv_loss_fwd_bwd(const void* x, const void* y, float c, float weight, float* 
                     int kind, int dtype, void* stream);
 /* x *= factor * (factor_dev ? factor_dev[0] : 1) */
 int mv_scale(void* x, const float* factor_dev, float factor, long n, int dtype, void* stream);
+/* y = x * factor * (factor_dev ? factor_dev[0] : 1), out of place (loss backward: the saved gradient times the upstream scalar). */
+int mv_scale_to(const void* x, void* y, const float* factor_dev, float factor, long n, int dtype, void* stream);
 
 /* Log-mel spectrogram (+ L1 loss against `target`, fp32 [B][n_mels][T/hop]) of wave [B][1][T]; defined by this build (the
  * reference has only placeholders: complete_vocoder.py:210-212, conditioned_hifigan.py:269-274).  Frames: reflect pad
