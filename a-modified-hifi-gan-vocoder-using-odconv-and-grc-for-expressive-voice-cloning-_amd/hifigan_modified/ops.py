@@ -516,12 +516,33 @@ def grc_fold_bwd(g_weff, g_beff, conv_w, conv_b, lora_A, lora_B, lora_scaling, p
     return outs
 
 
+class _ScalarArena:
+    """fp32 accumulators for the loss kernels: slots of one zero-filled block (one fill per 1024 losses instead of one per loss).
+    A slot is handed out once; the views keep their block alive.  Not used while a stream is being captured (a replay would not
+    re-zero the slots)."""
+
+    def __init__(self):
+        self.buf, self.i = None, 0
+
+    def take(self, device):
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(1, device=device, dtype=torch.float32)
+        if self.buf is None or self.i >= self.buf.numel() or self.buf.device != device:
+            self.buf, self.i = torch.zeros(1024, device=device, dtype=torch.float32), 0
+        v = self.buf[self.i:self.i + 1]
+        self.i += 1
+        return v
+
+
+_scalars = _ScalarArena()
+
+
 def loss_fwd_bwd(x, y, kind, c=0.0, weight=1.0, want_gx=True, want_gy=False, acc=None):
     """Returns (loss_acc fp32 [1], gx, gy).  acc: existing accumulator to add into."""
     x = _c(x)
     y = _c(y)
     if acc is None:
-        acc = torch.zeros(1, device=x.device, dtype=torch.float32)
+        acc = _scalars.take(x.device)
     gx = torch.empty_like(x) if want_gx else None
     gyt = torch.empty_like(x) if want_gy else None
     N.call("mv_loss_fwd_bwd", _p(x), _p(y), float(c), float(weight), _p(acc), _p(gx), _p(gyt), x.numel(), kind, _dt(x), _stream())
@@ -547,7 +568,7 @@ def mel_loss(wave, fb, target=None, n_fft=1024, hop=256, clampv=1e-5, weight=1.0
     wave = _c(wave)
     B, _, T = wave.shape
     n_mels = fb.shape[0]
-    acc = torch.zeros(1, device=wave.device, dtype=torch.float32)
+    acc = _scalars.take(wave.device)
     mel = _f32(B, n_mels, T // hop, device=wave.device) if want_mel else None
     gwave = torch.zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None
     if target is not None:
