@@ -81,9 +81,9 @@ class HiFiGANDiscriminators(nn.Module):
                 and torch.is_grad_enabled() and not real_audio.requires_grad and not fake_audio.requires_grad):
             both = Fn.batch_cat(real_audio, fake_audio)
             B = real_audio.shape[0]
-            mpd, msd = self.mpd(both), self.msd(both)
-            return {"mpd_real": [o[:B] for o in mpd], "mpd_fake": [o[B:] for o in mpd],
-                    "msd_real": [o[:B] for o in msd], "msd_fake": [o[B:] for o in msd]}
+            mpd, msd = [Fn.batch_split(o) for o in self.mpd(both)], [Fn.batch_split(o) for o in self.msd(both)]
+            return {"mpd_real": [r for r, _ in mpd], "mpd_fake": [f for _, f in mpd],
+                    "msd_real": [r for r, _ in msd], "msd_fake": [f for _, f in msd]}
         return {
             "mpd_real": self.mpd(real_audio),
             "mpd_fake": self.mpd(fake_audio),

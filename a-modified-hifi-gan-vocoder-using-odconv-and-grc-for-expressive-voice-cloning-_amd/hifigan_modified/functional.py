@@ -390,6 +390,36 @@ def batch_cat(a, b):
     return _BatchCat.apply(a, b)
 
 
+class _BatchSplit(Function):
+    """The two halves of a batch as views; backward writes the two gradients into one buffer (two strided copies) instead of the
+    zeros + copy per slice and the add that autograd's own slicing builds."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        ctx.shape, ctx.B = x.shape, x.shape[0] // 2
+        return x[:ctx.B], x[ctx.B:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        if ref is None:
+            return None
+        g = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype)
+        n = g.numel() // 2
+        halves = g.view(2, 1, n)
+        for i, gh in enumerate((ga, gb)):
+            if gh is None:
+                halves[i:i + 1].zero_()
+            else:
+                ops.copy_rows((gh if gh.is_contiguous() else gh.contiguous()).view(1, 1, n), halves[i:i + 1])
+        return g
+
+
+def batch_split(x):
+    return _BatchSplit.apply(x)
+
+
 def _grc_generic(x, blk):
     """grc_lora.py:32-68 with the parameter algebra folded: conv_g + LoRA + 1x1 -> one dense dilated conv."""
     k, d = blk.kernel_size, blk.dilation
