@@ -139,6 +139,44 @@ __global__ __launch_bounds__(256) void odconv_wgrad_reduce_kernel(const float* _
   for (int i = threadIdx.x; i < B * K; i += blockDim.x) atomicAdd(galpha + i, dots[i]);
 }
 
+// Same reduction, 4 consecutive elements per thread (K <= 4, nelem % 4 == 0): one 16-byte load of the sample's tile per step, and the
+// B x K wave reductions of the alpha-gradient dots run once per 4 elements instead of once per element (they were the bulk of the
+// instruction count: 6 shuffles per (sample, bank) against one load and K FMAs).
+template <typename T>
+__global__ __launch_bounds__(256) void odconv_wgrad_reduce4_kernel(const float* __restrict__ gws, const T* __restrict__ w,
+                                                                   const float* __restrict__ alpha, float* __restrict__ gw,
+                                                                   float* __restrict__ galpha, int B, int K, long nelem) {
+  extern __shared__ float dots[];              // [B][K]
+  for (int i = threadIdx.x; i < B * K; i += blockDim.x) dots[i] = 0.f;
+  __syncthreads();
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool ok = e < nelem;
+  const int lane = threadIdx.x & 63;
+  float wk[4][4], acc[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wk[k][j] = (ok && k < K) ? ld<T>(w + (long)k * nelem + e + j) : 0.f; acc[k][j] = 0.f; }
+  for (int b = 0; b < B; ++b) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) g = *reinterpret_cast<const float4*>(gws + (long)b * nelem + e);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < K) {
+        const float a = alpha[b * K + k];
+        acc[k][0] += a * g.x; acc[k][1] += a * g.y; acc[k][2] += a * g.z; acc[k][3] += a * g.w;
+        const float d = wave_sum(g.x * wk[k][0] + g.y * wk[k][1] + g.z * wk[k][2] + g.w * wk[k][3]);
+        if (lane == 0) atomicAdd(dots + b * K + k, d);
+      }
+  }
+  if (ok)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < K) *reinterpret_cast<float4*>(gw + (long)k * nelem + e) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < B * K; i += blockDim.x) atomicAdd(galpha + i, dots[i]);
+}
+
 // rowsum[b][o] = sum_t gy[b,o,t]
 template <typename T>
 __global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ gy, float* __restrict__ out, int C, int Tn,
@@ -512,10 +550,15 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
                        (const T*)w, alpha, dst, galpha, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, nbanks, x_bs, x_cs,
                        g_bs, g_cs, tsplit, tchunk, per_sample);
     if (per_sample) {
-      const int epb = 256;       // one element per thread: the B x K wave reductions of a block stay short
-      hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
-                         sizeof(float) * B * nbanks, (hipStream_t)stream, workspace, (const T*)w, alpha, gw, galpha, B,
-                         nbanks, nelem, epb);
+      if (nbanks <= 4 && nelem % 4 == 0 && (((uintptr_t)workspace | (uintptr_t)gw) & 15) == 0) {
+        hipLaunchKernelGGL(odconv_wgrad_reduce4_kernel<T>, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256),
+                           sizeof(float) * B * nbanks, (hipStream_t)stream, workspace, (const T*)w, alpha, gw, galpha, B, nbanks, nelem);
+      } else {
+        const int epb = 256;       // one element per thread: the B x K wave reductions of a block stay short
+        hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
+                           sizeof(float) * B * nbanks, (hipStream_t)stream, workspace, (const T*)w, alpha, gw, galpha, B,
+                           nbanks, nelem, epb);
+      }
     }
   });
   MV_LAUNCH_CHECK();
@@ -525,6 +568,12 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
 extern "C" int mv_odconv_wgrad_reduce(const float* gws, const void* w, const float* alpha, float* gw, float* galpha, int B, int K,
                                       long nelem, int dtype, void* stream) {
   MV_CHECK_ARG(gws && w && alpha && gw && galpha && B > 0 && K >= 1 && K <= 8 && nelem > 0);
+  if (K <= 4 && nelem % 4 == 0 && (((uintptr_t)gws | (uintptr_t)gw) & 15) == 0) {
+    MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_wgrad_reduce4_kernel<T>, dim3((unsigned)((nelem / 4 + 255) / 256)), dim3(256),
+                                          sizeof(float) * B * K, (hipStream_t)stream, gws, (const T*)w, alpha, gw, galpha, B, K, nelem));
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   const int epb = 256;
   MV_DISPATCH(dtype, hipLaunchKernelGGL(odconv_wgrad_reduce_kernel<T>, dim3((unsigned)((nelem + epb - 1) / epb)), dim3(256),
                                         sizeof(float) * B * K, (hipStream_t)stream, gws, (const T*)w, alpha, gw, galpha, B, K, nelem, epb));
