@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const T* __restrict__ x, co
 }
 
 // ---------------------------------------------------------------- GRC + LoRA weight fold (grc_lora.py:33-57)
-template <typename T>
+template <typename T, bool LDS>
 __global__ __launch_bounds__(256) void grc_fold_kernel(const T* __restrict__ conv_w, const T* __restrict__ conv_b,
                                                        const T* __restrict__ A, const T* __restrict__ Bm,
                                                        const T* __restrict__ scal, const T* __restrict__ proj_w,
@@ -421,7 +421,21 @@ __global__ __launch_bounds__(256) void grc_fold_kernel(const T* __restrict__ con
   const int total = Cout * Cin * ks;
   const int cin_g = Cin / groups, cout_g = Cout / groups;
   const float s = ld<T>(scal);
-  if (idx < total) {
+  // the four small operands go to LDS first (all their loads in flight together): read element by element from global inside the
+  // Cout x rank loop nest below they were a chain of dependent L2 round trips (34 us for 3840 outputs)
+  extern __shared__ float gsm[];
+  float* Al = gsm;                                   // [Cin][rank]
+  float* Bl = Al + Cin * rank;                       // [rank][Cout]
+  float* Pl = Bl + rank * Cout;                      // [Cout][Cout]
+  float* Wl = Pl + Cout * Cout;                      // [Cout][cin_g][ks]
+  if (LDS) {
+    for (int i = threadIdx.x; i < Cin * rank; i += blockDim.x) Al[i] = ld<T>(A + i);
+    for (int i = threadIdx.x; i < rank * Cout; i += blockDim.x) Bl[i] = ld<T>(Bm + i);
+    for (int i = threadIdx.x; i < Cout * Cout; i += blockDim.x) Pl[i] = ld<T>(proj_w + i);
+    for (int i = threadIdx.x; i < Cout * cin_g * ks; i += blockDim.x) Wl[i] = ld<T>(conv_w + i);
+    __syncthreads();
+  }
+  if (!LDS && idx < total) {                         // operands too large for LDS: straight from global
     const int j = idx % ks, c = (idx / ks) % Cin, o = idx / (ks * Cin);
     float acc = 0.f;
     for (int op = 0; op < Cout; ++op) {
@@ -434,6 +448,22 @@ __global__ __launch_bounds__(256) void grc_fold_kernel(const T* __restrict__ con
         comb += s * l;
       }
       acc += ld<T>(proj_w + (long)o * Cout + op) * comb;
+    }
+    st<T>(w_eff + idx, acc);
+  }
+  if (LDS && idx < total) {
+    const int j = idx % ks, c = (idx / ks) % Cin, o = idx / (ks * Cin);
+    float acc = 0.f;
+    for (int op = 0; op < Cout; ++op) {
+      float comb = 0.f;
+      const int g = op / cout_g;
+      if (c / cin_g == g) comb = Wl[(op * cin_g + (c - g * cin_g)) * ks + j];
+      if (j == ks / 2) {
+        float l = 0.f;
+        for (int r = 0; r < rank; ++r) l += Al[c * rank + r] * Bl[r * Cout + op];
+        comb += s * l;
+      }
+      acc += Pl[o * Cout + op] * comb;
     }
     st<T>(w_eff + idx, acc);
   }
@@ -663,10 +693,18 @@ extern "C" int mv_grc_fold_weights(const void* conv_w, const void* conv_b, const
   MV_CHECK_ARG(conv_w && conv_b && lora_A && lora_B && lora_scaling && proj_w && proj_b && w_eff && b_eff);
   MV_CHECK_ARG(Cin > 0 && Cout > 0 && ks > 0 && (ks & 1) && groups > 0 && Cin % groups == 0 && Cout % groups == 0 && rank > 0);
   const int total = Cout * Cin * ks;
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(grc_fold_kernel<T>, dim3(cdiv(total > Cout ? total : Cout, 256)), dim3(256), 0,
-                                        (hipStream_t)stream, (const T*)conv_w, (const T*)conv_b, (const T*)lora_A,
-                                        (const T*)lora_B, (const T*)lora_scaling, (const T*)proj_w, (const T*)proj_b,
-                                        (T*)w_eff, (T*)b_eff, Cin, Cout, ks, groups, rank));
+  const size_t flds = sizeof(float) * ((size_t)Cin * rank + (size_t)rank * Cout + (size_t)Cout * Cout + (size_t)Cout * (Cin / groups) * ks);
+  if (flds <= 48 * 1024) {
+    MV_DISPATCH(dtype, hipLaunchKernelGGL((grc_fold_kernel<T, true>), dim3(cdiv(total > Cout ? total : Cout, 256)), dim3(256), flds,
+                                          (hipStream_t)stream, (const T*)conv_w, (const T*)conv_b, (const T*)lora_A,
+                                          (const T*)lora_B, (const T*)lora_scaling, (const T*)proj_w, (const T*)proj_b,
+                                          (T*)w_eff, (T*)b_eff, Cin, Cout, ks, groups, rank));
+  } else {
+    MV_DISPATCH(dtype, hipLaunchKernelGGL((grc_fold_kernel<T, false>), dim3(cdiv(total > Cout ? total : Cout, 256)), dim3(256), 0,
+                                          (hipStream_t)stream, (const T*)conv_w, (const T*)conv_b, (const T*)lora_A,
+                                          (const T*)lora_B, (const T*)lora_scaling, (const T*)proj_w, (const T*)proj_b,
+                                          (T*)w_eff, (T*)b_eff, Cin, Cout, ks, groups, rank));
+  }
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

@@ -54,19 +54,29 @@ __global__ __launch_bounds__(1024) void grc_fold_bwd_kernel(const float* __restr
   float* gwl = red + 32;                     // [Cout][Cin][ks] copy of g_weff: every later loop re-reads it many times
   const int tid = threadIdx.x, nt = blockDim.x;
   const int cin_g = Cin / groups, cout_g = Cout / groups, mid = ks / 2;
+  // parameter copies in LDS: the loops below are chains of dependent reads (192 per g_proj_w element) - out of global memory
+  // each link was an L2 round trip (44 us for the whole kernel)
+  float* Wl = gwl + Cout * Cin * ks;         // conv_w [Cout][cin_g][ks]
+  float* Pl = Wl + Cout * cin_g * ks;        // proj_w [Cout][Cout]
+  float* Al = Pl + Cout * Cout;              // A [Cin][rank]
+  float* Bl = Al + Cin * rank;               // B [rank][Cout]
   const float s = ld<P>(scal);
   for (int i = tid; i < Cout * Cin * ks; i += nt) gwl[i] = g_weff[i];
+  for (int i = tid; i < Cout * cin_g * ks; i += nt) Wl[i] = ld<P>(conv_w + i);
+  for (int i = tid; i < Cout * Cout; i += nt) Pl[i] = ld<P>(proj_w + i);
+  for (int i = tid; i < Cin * rank; i += nt) Al[i] = ld<P>(A + i);
+  for (int i = tid; i < rank * Cout; i += nt) Bl[i] = ld<P>(Bm + i);
   __syncthreads();
   for (int i = tid; i < Cin * Cout; i += nt) {
     const int c = i / Cout, o = i % Cout;
     float l = 0.f;
-    for (int r = 0; r < rank; ++r) l += ld<P>(A + c * rank + r) * ld<P>(Bm + r * Cout + o);
+    for (int r = 0; r < rank; ++r) l += Al[c * rank + r] * Bl[r * Cout + o];
     L[i] = l;
   }
   for (int i = tid; i < Cout * Cin * ks; i += nt) {
     const int j = i % ks, c = (i / ks) % Cin, op = i / (ks * Cin);
     float a = 0.f;
-    for (int o = 0; o < Cout; ++o) a += ld<P>(proj_w + o * Cout + op) * gwl[(o * Cin + c) * ks + j];
+    for (int o = 0; o < Cout; ++o) a += Pl[o * Cout + op] * gwl[(o * Cin + c) * ks + j];
     gcomb[i] = a;
   }
   __syncthreads();
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(1024) void grc_fold_bwd_kernel(const float* __restr
     for (int c = 0; c < Cin; ++c)
       for (int j = 0; j < ks; ++j) {
         float comb = 0.f;
-        if (c / cin_g == g) comb = ld<P>(conv_w + ((long)op * cin_g + (c - g * cin_g)) * ks + j);
+        if (c / cin_g == g) comb = Wl[(op * cin_g + (c - g * cin_g)) * ks + j];
         if (j == mid) comb += s * L[c * Cout + op];
         a += gwl[(o * Cin + c) * ks + j] * comb;
       }
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(1024) void grc_fold_bwd_kernel(const float* __restr
   for (int o = tid; o < Cout; o += nt) {
     g_proj_b[o] = g_beff[o];
     float a = 0.f;
-    for (int oo = 0; oo < Cout; ++oo) a += ld<P>(proj_w + oo * Cout + o) * g_beff[oo];
+    for (int oo = 0; oo < Cout; ++oo) a += Pl[oo * Cout + o] * g_beff[oo];
     g_conv_b[o] = a;
   }
   for (int i = tid; i < Cout * cin_g * ks; i += nt) {
@@ -98,13 +108,13 @@ __global__ __launch_bounds__(1024) void grc_fold_bwd_kernel(const float* __restr
   for (int i = tid; i < Cin * rank; i += nt) {
     const int c = i / rank, r = i % rank;
     float a = 0.f;
-    for (int op = 0; op < Cout; ++op) a += s * gcomb[((long)op * Cin + c) * ks + mid] * ld<P>(Bm + r * Cout + op);
+    for (int op = 0; op < Cout; ++op) a += s * gcomb[((long)op * Cin + c) * ks + mid] * Bl[r * Cout + op];
     g_A[i] = a;
   }
   for (int i = tid; i < rank * Cout; i += nt) {
     const int r = i / Cout, op = i % Cout;
     float a = 0.f;
-    for (int c = 0; c < Cin; ++c) a += ld<P>(A + c * rank + r) * s * gcomb[((long)op * Cin + c) * ks + mid];
+    for (int c = 0; c < Cin; ++c) a += Al[c * rank + r] * s * gcomb[((long)op * Cin + c) * ks + mid];
     g_B[i] = a;
   }
   float part = 0.f;
@@ -356,7 +366,8 @@ extern "C" int mv_grc_fold_bwd(const float* g_weff, const float* g_beff, const v
                                void* stream) {
   MV_CHECK_ARG(g_weff && g_beff && conv_w && conv_b && lora_A && lora_B && lora_scaling && proj_w);
   MV_CHECK_ARG(g_conv_w && g_conv_b && g_A && g_B && g_s && g_proj_w && g_proj_b && (ks & 1) && Cin % groups == 0 && Cout % groups == 0);
-  const size_t lds = sizeof(float) * (2 * (size_t)Cout * Cin * ks + (size_t)Cin * Cout + 32);
+  const size_t lds = sizeof(float) * (2 * (size_t)Cout * Cin * ks + (size_t)Cin * Cout + 32 + (size_t)Cout * (Cin / groups) * ks +
+                                      (size_t)Cout * Cout + (size_t)Cin * rank + (size_t)rank * Cout);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
 #define GO(P) { auto kern = grc_fold_bwd_kernel<P>; \
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
