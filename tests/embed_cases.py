@@ -3,8 +3,6 @@ tests/golden/embed_weights.py (checked against the checksum stored in the fixtur
 import os
 import sys
 
-import torch
-
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from embed_weights import fill_state, state_checksum      # noqa: E402
 
