@@ -815,6 +815,24 @@ __global__ __launch_bounds__(256) void dconv_wgrad_reorder_kernel(const float* _
   }
 }
 
+// The same reorder for a workspace that STAYS zero between calls: every element read is cleared (each is read exactly once), the
+// bias sums behind the weights are handed out and cleared too - the next weight gradient needs no fill launch.
+__global__ __launch_bounds__(256) void dconv_wgrad_finalize_kernel(float* __restrict__ gws, float* __restrict__ gw, float* __restrict__ gb,
+                                                                   int OC, int taps, int Cout) {
+  const long total = (long)OC * taps;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total + Cout; i += (long)gridDim.x * blockDim.x) {
+    if (i < total) {
+      const int tap = (int)(i % taps);
+      const long src = (long)tap * OC + i / taps;
+      gw[i] = gws[src];
+      gws[src] = 0.f;
+    } else {
+      if (gb) gb[i - total] = gws[i];
+      gws[i] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ first layer (1 -> C1 channels)
 // forward: a1[pos][o] = lrelu(b[o] + sum_tap w[o][tap] x0[pos+tap]);  x0 [B][H][W] (one channel), a1 [B][H][W][C1]
 template <typename T>
@@ -1265,6 +1283,24 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
   MV_LAUNCH_CHECK();
   return MV_OK;
 }
+
+extern "C" int mv_dconv_wgrad_cl_pz(const void* x, const void* g, float* gw, float* gb, float* workspace, int B, int H, int W, int Cin,
+                                    int Cout, int kh, int kw, int dil_w, int dtype, void* stream) {
+  MV_CHECK_ARG(x && g && gw && workspace && B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && dil_w >= 1);
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)g & 15) == 0);
+  if (dtype == MV_F32) return MV_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)Cout * Cin * kh * kw;
+  int rc = MV_ERR_UNSUPPORTED;
+  if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, workspace + total, B, H, W, Cin, Cout, kh, kw, dil_w, s);
+  else if (dtype == MV_F16) rc = dwgrad_dispatch<f16>(x, g, workspace, workspace + total, B, H, W, Cin, Cout, kh, kw, dil_w, s);
+  if (rc != MV_OK) return rc;
+  hipLaunchKernelGGL(dconv_wgrad_finalize_kernel, dim3((unsigned)((total + Cout + 255) / 256 > 2048 ? 2048 : (total + Cout + 255) / 256)),
+                     dim3(256), 0, s, workspace, gw, gb, Cout * Cin, kh * kw, Cout);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
 
 // ------------------------------------------------------------------------------------------------ tap matrix (im2col of a one-channel map)
 // out[pos][tap] (16 taps per position, zero beyond kh*kw) = sc[pos + off(tap)]  (flip = 0)  or  sc[pos - off(tap)]  (flip = 1),

@@ -189,11 +189,8 @@ class _DiscStack(Function):
         for li in (3, 2, 1):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             if need_w:
-                gw = f32(Cout, Cin, kh, kw)
-                wsb = f32(kh * kw * Cout * Cin + Cout)        # tap-major workspace | bias sums: one fill in the entry point
-                gb = wsb[kh * kw * Cout * Cin:]
-                N.call("mv_dconv_wgrad_cl", _P(acts[li - 1]), _P(g), _P(gw), _P(gb), _P(wsb), B, H, W, Cin, Cout, kh, kw, 1,
-                       ops._dt(g), st())
+                gw, gb = f32(Cout, Cin, kh, kw), f32(Cout)
+                ops.wgrad_cl_into(acts[li - 1], g, gw, gb, B, H, W, Cin, Cout, kh, kw, 1)
                 grads[2 * li], grads[2 * li + 1] = to(gw, params[2 * li]), to(gb, params[2 * li + 1])
             gprev = torch.empty(B, H, W, Cin, device=dev, dtype=dt)
             N.call("mv_dconv_cl_fwd", _P(g), _P(_packs.get(params[2 * li], dt, 1)), None, _P(acts[li - 1]), _P(gprev), B, H, W, Cout, Cin,

@@ -370,16 +370,40 @@ def dconv_cl(x_cl, packed, bias, Cout, kh, kw, dil=1, act=N.ACT_NONE, slope=0.1,
     return y
 
 
+_WGRAD_WS = {}        # (device, stream, floats) -> workspace kept zero between weight-gradient calls
+
+
+def wgrad_cl_into(x_cl, g_cl, gw, gb, B, H, W, Cin, Cout, kh, kw, dil):
+    """mv_dconv_wgrad_cl_pz on a persistent workspace (zero between calls: its reorder pass clears what it reads); falls back to the
+    fill-per-call entry while a stream is being captured.  gb may be None."""
+    dev = x_cl.device
+    n = kh * kw * Cout * Cin + Cout
+    if torch.cuda.is_current_stream_capturing():
+        ws = _f32(n, device=dev)
+        N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(ws[n - Cout:]) if gb is not None else None, _p(ws), B, H, W, Cin, Cout,
+               kh, kw, dil, _dt(x_cl), _stream())
+        if gb is not None:
+            gb.copy_(ws[n - Cout:])
+        return
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, n)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.zeros(n, device=dev, dtype=torch.float32)
+    try:
+        N.call("mv_dconv_wgrad_cl_pz", _p(x_cl), _p(g_cl), _p(gw), _p(gb), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
+    except Exception:
+        _WGRAD_WS.pop(key, None)      # the workspace may be dirty: never reuse it
+        raise
+
+
 def dconv_wgrad_cl(x_cl, g_cl, kh, kw, dil=1, want_bias=False):
     """fp32 [Cout,Cin,kh,kw] = sum_pos g x (transposed-LDS-read MFMA GEMM); with want_bias also gb fp32 [Cout] = sum_pos g."""
     shp = x_cl.shape
     B, H, W, Cin = (shp[0], 1, shp[1], shp[2]) if x_cl.dim() == 3 else shp
     Cout = g_cl.shape[-1]
     gw = _f32(Cout, Cin, kh, kw, device=x_cl.device)
-    wn = kh * kw * Cout * Cin
-    ws = _f32(wn + (Cout if want_bias else 0), device=x_cl.device)     # tap-major workspace | bias sums: zeroed by ONE fill in the entry
-    gb = ws[wn:] if want_bias else None
-    N.call("mv_dconv_wgrad_cl", _p(x_cl), _p(g_cl), _p(gw), _p(gb), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
+    gb = _f32(Cout, device=x_cl.device) if want_bias else None
+    wgrad_cl_into(x_cl, g_cl, gw, gb, B, H, W, Cin, Cout, kh, kw, dil)
     return (gw, gb) if want_bias else gw
 
 

@@ -339,6 +339,10 @@ int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, in
 size_t mv_dconv_wgrad_workspace_bytes(int Cin, int Cout, int kh, int kw);
 int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float* gb, float* workspace, int B, int H, int W, int Cin,
                       int Cout, int kh, int kw, int dil_w, int dtype, void* stream);
+/* The same with a workspace the caller keeps between calls: (Cout*Cin*kh*kw + Cout) floats, ZERO on entry, zero again on exit (the
+ * reorder pass clears what it reads), so no fill launch is needed per call.  gb (may be NULL) receives the bias sums. */
+int mv_dconv_wgrad_cl_pz(const void* x, const void* g, float* gw, float* gb, float* workspace, int B, int H, int W, int Cin,
+                         int Cout, int kh, int kw, int dil_w, int dtype, void* stream);
 
 /* First discriminator layer (1 -> C1 channels, LeakyReLU), channels-last output, and its gradients
  * (discriminators.py:57 / :98 with Cin = 1): x0 [B][H][W], w [C1][kh*kw] (= the [C1,1,kh,kw] parameter), a1/g1 [B][H][W][C1]. */
