@@ -48,6 +48,25 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const P* __restrict__ w
   }
 }
 
+// Many weight tensors packed by ONE launch (after an optimizer step every conv weight of the stepped module changes at once):
+// blockIdx.y selects the tensor, the body is dconv_pack_kernel's for fp32 masters with no channel padding.
+struct MultiPackDesc { const float* src; void* dst; int Cout, Cin, kh, kw, flip, dtype; };
+__global__ __launch_bounds__(256) void dconv_multi_pack_kernel(const MultiPackDesc* __restrict__ descs) {
+  const MultiPackDesc d = descs[blockIdx.y];
+  const int M = d.flip ? d.Cin : d.Cout, Kc = d.flip ? d.Cout : d.Cin;
+  const int taps = d.kh * d.kw, cpc = Kc / 8, ksteps = taps * (Kc / 32);
+  const long total = (long)(M / 16) * ksteps * 512;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = idx % 8, lane = (idx / 8) % 64;
+    const long fr = idx / 512;
+    const int kstep = fr % ksteps, mt = fr / ksteps;
+    const int row = 16 * mt + (lane & 15), chunk = 4 * kstep + (lane >> 4);
+    const int tap = chunk / cpc, c = 8 * (chunk % cpc) + j;
+    const float v = !d.flip ? d.src[((long)row * d.Cin + c) * taps + tap] : d.src[((long)c * d.Cin + row) * taps + (taps - 1 - tap)];
+    if (d.dtype == MV_BF16) st<bf16>((bf16*)d.dst + idx, v); else st<f16>((f16*)d.dst + idx, v);
+  }
+}
+
 template <typename T, int NWV, int MW, int NB>
 __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                        const T* __restrict__ bias, const T* __restrict__ actsave,
@@ -1044,6 +1063,13 @@ extern "C" int mv_dconv_pack(const void* w, int param_dtype, void* packed, int C
                              int dtype, void* stream) {
   MV_CHECK_ARG(Cout % 16 == 0 && Cin % 32 == 0);
   return mv_dconv_pack_pad(w, param_dtype, packed, Cout, Cin, kh, kw, Cout, Cin, flip, dtype, stream);
+}
+
+extern "C" int mv_dconv_multi_pack(const void* descs_dev, int n, void* stream) {
+  MV_CHECK_ARG(descs_dev && n > 0 && n <= 65535);
+  hipLaunchKernelGGL(dconv_multi_pack_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const MultiPackDesc*)descs_dev);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
 }
 
 template <typename T, int NWV, int MW, int NB>

@@ -124,6 +124,8 @@ class VocoderTrainer:
                 self.grad_sync.start(flat)
                 scale = self.grad_sync.finish()
             opt.step(grad_scale=scale, gathered=True)
+            from . import disc_fused
+            disc_fused._packs.refresh_owned(opt)     # all conv packs of the stepped module in one launch
         else:
             opt.step()
 

@@ -42,6 +42,36 @@ class _PackCache:
         self.d[key] = (weakref.ref(param), ver, buf)
         return buf
 
+    def refresh_owned(self, opt):
+        """After `opt.step()` (flat-arena AdamW): re-pack every plain conv pack whose fp32 master belongs to `opt` with ONE launch and
+        mark the entries current - instead of one pack launch per layer and direction as the layers run."""
+        import numpy as np
+        ents = []
+        for key, e in self.d.items():
+            kind, p = key[1], e[0]()
+            if (p is None or not isinstance(kind, tuple) or len(kind) != 2 or kind[0] not in (torch.bfloat16, torch.float16)
+                    or p.dtype != torch.float32 or not p.is_contiguous() or not opt.owns(p)):
+                continue
+            w = _as4d(p)
+            if w.shape[0] % 16 or w.shape[1] % 32:
+                continue
+            ents.append((key, p, e[2], kind, w.shape))
+        if not ents:
+            return 0
+        sig = tuple((id(p), p.data_ptr(), buf.data_ptr()) for _, p, buf, _, _ in ents)
+        hit = self.__dict__.setdefault("_mp", {}).get(id(opt))
+        if hit is None or hit[0] != sig:
+            d = np.zeros(len(ents), dtype=[("src", "u8"), ("dst", "u8"), ("cout", "i4"), ("cin", "i4"), ("kh", "i4"), ("kw", "i4"),
+                                           ("flip", "i4"), ("dtype", "i4")])
+            for i, (_, p, buf, kind, shp) in enumerate(ents):
+                d[i] = (p.data_ptr(), buf.data_ptr(), shp[0], shp[1], shp[2], shp[3], int(kind[1]), ops._DT[kind[0]])
+            table = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(ents[0][1].device)
+            hit = self._mp[id(opt)] = (sig, table)
+        N.call("mv_dconv_multi_pack", _P(hit[1]), len(ents), ops._stream())
+        for key, p, buf, _, _ in ents:
+            self.d[key] = (weakref.ref(p), (p._version, ops.param_epoch_of(p), p.data_ptr()), buf)
+        return len(ents)
+
     def get(self, param, dtype, flip):
         key, ver, buf = self._lookup(param, (dtype, flip))
         if buf is not None:

@@ -318,6 +318,10 @@ int mv_dropout_mask(uint8_t* mask, long n, float p, long seed, void* stream);
 size_t mv_dconv_packed_bytes(int Cout, int Cin, int kh, int kw, int dtype);
 int mv_dconv_pack(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int flip, int dtype,
                   void* stream);
+/* n weight tensors packed by one launch.  descs_dev: device array of { const float* src; void* dst; int Cout, Cin, kh, kw, flip, dtype; }
+ * (40 bytes each): src = fp32 [Cout][Cin][kh][kw] with Cout % 16 == 0 and Cin % 32 == 0 (no padding), dst = mv_dconv_packed_bytes image,
+ * dtype MV_BF16 / MV_F16.  Same result as n mv_dconv_pack calls. */
+int mv_dconv_multi_pack(const void* descs_dev, int n, void* stream);
 /* mv_dconv_pack with the operator zero-padded to Coutp x Cinp channels (multiples of 32 for the side that is contracted). */
 int mv_dconv_pack_pad(const void* w, int param_dtype, void* packed, int Cout, int Cin, int kh, int kw, int Coutp, int Cinp,
                       int flip, int dtype, void* stream);
