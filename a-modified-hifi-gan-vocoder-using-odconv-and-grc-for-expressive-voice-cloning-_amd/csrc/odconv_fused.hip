@@ -35,6 +35,7 @@ struct OdP {
   int shift_lo;   // lowest input-row shift: -pad (conv) or -(ntaps-1) (transposed)
   int nrows;      // LDS rows per sample tile
   int film_F;
+  int pool_n;     // floats per sample in pooled_in: slots * rows partial sums of the producing launch (Cin = dense sums)
 };
 
 template <typename T> struct WLoad;   // this lane's 8 packed weights -> fp32
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       const int s = pr / p.K, kb = pr % p.K;
       float acc = 0.f;
       if (b0 + s < p.B)
-        for (int c = lane; c < p.Cin; c += 64) acc += ld<T>(att_w + (long)kb * p.Cin + c) * pooled_in[(long)(b0 + s) * p.Cin + c];
+        for (int i = lane; i < p.pool_n; i += 64)    // fixed summation order over the producer's partial sums: deterministic
+          acc += ld<T>(att_w + (long)kb * p.Cin + i % p.Cin) * pooled_in[(long)(b0 + s) * p.pool_n + i];
       acc = wave_sum(acc);
       if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
     }
@@ -339,10 +341,10 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
             rowsum[i] = v;
           }
           if (pooled_out && col == 0 && mt < n_mt && b < p.B) {
+            // partial sums of this workgroup's column block, one slot per blockIdx.x: written once, summed by the consumer
             const int row = 16 * mt + 4 * g;
-            const int o = p.transposed ? row % p.Cout : row;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+            *reinterpret_cast<f32x4*>(pooled_out + ((long)b * gridDim.x + blockIdx.x) * p.M + row) =
+                f32x4{rowsum[0], rowsum[1], rowsum[2], rowsum[3]};
           }
         }
       }
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
   } else {
     for (int kb = wid; kb < p.K; kb += 4) {
       float a = 0.f;
-      for (int c = lane; c < CIN; c += 64) a += ld<T>(att_w + (long)kb * CIN + c) * pooled_in[(long)b * CIN + c];
+      for (int i = lane; i < p.pool_n; i += 64) a += ld<T>(att_w + (long)kb * CIN + i % CIN) * pooled_in[(long)b * p.pool_n + i];
       a = wave_sum(a);
       if (lane == 0) alds[kb] = a / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
     }
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
     }
     __syncthreads();                                           // output tile drained before the next x tile lands
   }
-  if (pooled_out) {                                            // one atomic per (row, workgroup) instead of one per tile
+  if (pooled_out) {                                            // one partial per (row, workgroup): slot blockIdx.x of this sample
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw) {
       const int mt = mt0 + mw;
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
         float v = psum[mw][i];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-        if (col == 0 && mt < n_mt) atomicAdd(pooled_out + (long)b * p.Cout + (16 * mt + 4 * g + i) % p.Cout, v);
+        if (col == 0 && mt < n_mt) pooled_out[((long)b * gridDim.x + blockIdx.x) * p.M + 16 * mt + 4 * g + i] = v;
       }
     }
   }
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
 
 template <typename T, int MW, int NB, int CIN>
 static int od_mt_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
-                        const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream) {
+                        const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream, int* slots_out) {
   constexpr int ES = 2;
   const int nrows = NB * 16 + 1;
   const size_t xbytes = (size_t)nrows * lds_row_stride(CIN * ES, ES);
@@ -605,6 +607,7 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   if (TL > 16) TL = 16;
   dim3 grid(cdiv(ntl, TL), gy, p.B);
   if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
+  if (slots_out) { *slots_out = (int)grid.x; return MV_OK; }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha,
                      pooled_in, (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p, TL);
   return MV_OK;
@@ -647,7 +650,8 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
       const int s = pr / p.K, kb = pr % p.K;
       float acc = 0.f;
       if (b0 + s < p.B)
-        for (int c = lane; c < p.Cin; c += 64) acc += ld<T>(att_w + (long)kb * p.Cin + c) * pooled_in[(long)(b0 + s) * p.Cin + c];
+        for (int i = lane; i < p.pool_n; i += 64)    // fixed summation order over the producer's partial sums: deterministic
+          acc += ld<T>(att_w + (long)kb * p.Cin + i % p.Cin) * pooled_in[(long)(b0 + s) * p.pool_n + i];
       acc = wave_sum(acc);
       if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
     }
@@ -808,11 +812,9 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
           for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
           rowsum[i] = v;
         }
-        if (col == 0 && mt < n_mt && b < p.B) {
+        if (col == 0 && mt < n_mt && b < p.B) {   // the K-loop kernel covers a sample's columns in one workgroup: one slot
           const int row = 16 * mt + 4 * g;
-          const int o = p.transposed ? row % p.Cout : row;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) atomicAdd(pooled_out + (long)b * p.Cout + o + i, rowsum[i]);
+          *reinterpret_cast<f32x4*>(pooled_out + (long)b * p.M + row) = f32x4{rowsum[0], rowsum[1], rowsum[2], rowsum[3]};
         }
       }
     }
@@ -845,7 +847,8 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
 
 template <typename T, int S, int NB>
 static int od_kloop_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
-                           const void* att_w, const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream) {
+                           const void* att_w, const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream,
+                           int* slots_out) {
   using M = Mma<T>;
   if (p.nq > NB * 16 || p.K > 4 || p.Cin % 32 || p.ksteps % 8 || p.nchunks != 4 * p.ksteps || p.ntaps > 2)
     return MV_ERR_UNSUPPORTED;
@@ -863,6 +866,7 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
   }
   dim3 grid(cdiv(p.M / 16, 4), cdiv(p.B, S));
   if (grid.y > 65535) return MV_ERR_UNSUPPORTED;
+  if (slots_out) { *slots_out = 1; return MV_OK; }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
                      (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p);
   return MV_OK;
@@ -871,7 +875,7 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
 template <typename T, int S, int MW, int NB, bool PFW, int KB>
 static int od_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
                      const void* att_w, const void* att_b, const void* film, void* y, float* pooled_out, OdP p,
-                     hipStream_t stream) {
+                     hipStream_t stream, int* slots_out) {
   using M = Mma<T>;
   p.nrows = NB * 16 + (p.ntaps - 1) * (p.transposed ? 1 : p.dil);
   const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
@@ -886,6 +890,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
   }
   dim3 grid(cdiv(p.nq, NB * 16), cdiv(p.M / 16, 4 * MW), cdiv(p.B, S));
   if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
+  if (slots_out) { *slots_out = (int)grid.x; return MV_OK; }
 #ifdef MV_OD_TIMING
   static long long* dbg = nullptr;
   static int calls = 0;
@@ -935,6 +940,7 @@ static bool od_make(OdP* p, int B, int Cin, int Tin, int Cout, int Tout, int ks,
   p->nchunks = p->ntaps * (Cin / 8);
   p->ksteps = cdiv(p->nchunks, 4);
   p->nrows = 0;
+  p->pool_n = Cin;
   return true;
 }
 
@@ -975,35 +981,30 @@ extern "C" int mv_odconv_cl_pack(const void* kernels, int param_dtype, void* pac
   return MV_OK;
 }
 
-extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha,
-                                const float* pooled_in, const void* att_w, const void* att_b, const void* film_proj,
-                                int film_F, void* y, float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout,
-                                int ks, int stride, int pad, int dil, int transposed, int K, int act, float slope,
-                                int dtype, void* stream) {
-  MV_CHECK_ARG(x && packed && y && (alpha || (pooled_in && att_w)));
-  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0);
-  OdP p;
-  if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, film_proj ? film_F : 0))
-    return MV_ERR_UNSUPPORTED;
+// Picks the kernel variant for a layer and launches it - or, with slots_out, only reports how many partial-sum slots per sample
+// that launch writes to pooled_out (the variant sets the grid, so the caller sizes pooled_out from the same decision).
+static int od_dispatch(const void* x, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
+                       const void* att_w, const void* att_b, const void* film_proj, void* y, float* pooled_out, OdP p,
+                       int dtype, hipStream_t st_, int* slots_out) {
+  const int K = p.K, B = p.B, Cin = p.Cin, transposed = p.transposed, act = p.act;
   const int ntiles = cdiv(p.nq, 16);
   const long wbytes = (long)K * p.M * p.ksteps * 32 * (dtype == MV_F32 ? 4 : 2);
   int rc = MV_ERR_DTYPE;
-  hipStream_t st_ = (hipStream_t)stream;
   // with the unconditional (clamped) prefetch the prefetching instantiation wins for the short-K upsamplers as well
   // (ups3 48 -> 44 us); MV_OD_PF=0 selects the non-prefetching one for comparison
   static int force_pf = -1;
   if (force_pf < 0) { const char* e = getenv("MV_OD_PF"); force_pf = e ? atoi(e) : 1; }
 #define OD_GO(S_, MW_, NB_) do { \
-    if (K <= 4 && p.ksteps <= 8 && !force_pf) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
-    else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); \
-    else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_); } while (0)
+    if (K <= 4 && p.ksteps <= 8 && !force_pf) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); \
+    else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); \
+    else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); } while (0)
   MV_DISPATCH(dtype, {
     if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler)
       rc = MV_ERR_UNSUPPORTED;
       if (!film_proj && dtype != MV_F32 && wbytes > (4 << 20) && B >= 2)   // K-loop, weights-stationary over S samples
       {   // S = 2 measured best (two workgroups per CU overlap each other's LDS/L2 latency); S = 1 if the tiles do not fit
-        rc = od_kloop_launch<T, 2, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
-        if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+        rc = od_kloop_launch<T, 2, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(2, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
@@ -1016,7 +1017,7 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
         // the sample's 96-column tiles - the bank fragments are fetched from L2 and mixed once per (sample, row block) instead
         // of once per tile (37 -> 28.5 us; 144-column tiles without the x look-ahead measured 34 us)
         if (mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256)
-          rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+          rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 9);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
@@ -1028,8 +1029,8 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
         if (mt_on && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && (Cin == 64 || Cin == 128)) {
           // 128-column tiles for 64 input channels; 64-column tiles for 128 (8 resident A fragments per M-tile: the wider tile
           // would need > 256 VGPRs, i.e. one wave per SIMD - measured 42 vs 24.5 us)
-          if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
-          else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_);
+          if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+          else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
         }
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 8);
@@ -1037,7 +1038,37 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
     }
   });
 #undef OD_GO
+  return rc;
+}
+
+extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha,
+                                const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
+                                const void* film_proj, int film_F, void* y, float* pooled_out, int B, int Cin, int Tin,
+                                int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
+                                float slope, int dtype, void* stream) {
+  MV_CHECK_ARG(x && packed && y && (alpha || (pooled_in && att_w && pooled_in_count > 0 && pooled_in_count % Cin == 0)));
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0);
+  MV_CHECK_ARG(((uintptr_t)pooled_out & 15) == 0);
+  OdP p;
+  if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, film_proj ? film_F : 0))
+    return MV_ERR_UNSUPPORTED;
+  if (pooled_in) p.pool_n = pooled_in_count;
+  const int rc = od_dispatch(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, dtype,
+                             (hipStream_t)stream, nullptr);
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   return MV_OK;
+}
+
+extern "C" size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                                         int transposed, int K, int act, int has_film, int dtype) {
+  OdP p;
+  if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, 0.1f, has_film ? 8 : 0)) return 0;
+  int slots = 0;
+  static const int dummy = 0;   // non-null stand-ins: the dry run launches nothing and touches no memory
+  const void* d = &dummy;
+  const int rc = od_dispatch(d, d, nullptr, nullptr, nullptr, nullptr, nullptr, has_film ? d : nullptr, nullptr, nullptr, p,
+                             dtype, nullptr, &slots);
+  if (rc != MV_OK || slots <= 0) return 0;
+  return (size_t)slots * p.M;
 }

@@ -191,7 +191,7 @@ class OdconvFused:
         B = gp.shape[0]
         P = lambda t: None if t is None else c_void_p(t.data_ptr())
         gx_cl = torch.empty(B, Tin, cin, device=gp.device, dtype=gp.dtype)
-        rc = N.lib().mv_odconv_cl_fwd(P(gp), P(self.packed_dgrad(gp.dtype, gp.device)), None, P(alpha), None, None, None, None, 0,
+        rc = N.lib().mv_odconv_cl_fwd(P(gp), P(self.packed_dgrad(gp.dtype, gp.device)), None, P(alpha), None, 0, None, None, None, 0,
                                       P(gx_cl), None, B, stride * cout, Tin + 1, cin, Tin, 2, 1, 0, 1, 0, K, int(N.ACT_NONE), 0.1,
                                       ops._dt(gp), ops._stream())
         if rc == -3:                         # MV_ERR_UNSUPPORTED: tile does not fit LDS (very wide adjoint input): the caller uses the generic HIP kernel
@@ -215,21 +215,34 @@ class OdconvFused:
         N.check(rc, "mv_odconvT_wgrad_mfma")
         return gw, galpha
 
+    def out_len(self, Tin):
+        m = self.mod
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        return (Tin - 1) * stride - 2 * pad + ks + m.output_padding if tr else Tin + 2 * pad - dil * (ks - 1)
+
+    def pool_floats(self, B, Tin, dtype, act=N.ACT_NONE, has_film=False):
+        """floats per sample of the partial-sum buffer (`pooled_out`) this layer's launch writes for its consumer's attention."""
+        cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
+        n = N.lib().mv_odconv_cl_pool_floats(B, cin, Tin, cout, self.out_len(Tin), ks, stride, pad, dil, int(tr), K, int(act),
+                                             int(has_film), ops._DT[dtype])
+        if n == 0:
+            raise RuntimeError("odconv_cl: unsupported geometry")
+        return n
+
     def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
                    act=N.ACT_NONE, slope=0.1):
+        """pooled_in / pooled_out: fp32 [B, n] partial channel sums (n = the producer's / this layer's pool_floats)."""
         m = self.mod
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         B, Tin, C = x_cl.shape
         assert C == cin and x_cl.is_contiguous()
-        if tr:
-            Tout = (Tin - 1) * stride - 2 * pad + ks + m.output_padding
-        else:
-            Tout = Tin + 2 * pad - dil * (ks - 1)
+        Tout = self.out_len(Tin)
         y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=x_cl.dtype)
         att = m.kernel_attention[1]
         P = lambda t: None if t is None else c_void_p(t.data_ptr())
         N.call("mv_odconv_cl_fwd", P(x_cl), P(self.packed(x_cl.dtype, x_cl.device)), P(cache.get(m.bias, x_cl.dtype)),
-               P(alpha), P(pooled_in), P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)),
+               P(alpha), P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
+               P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)),
                P(film_proj), int(film_F), P(y), P(pooled_out), B, cin, Tin, cout, Tout, ks, stride, pad, dil, int(tr), K,
                int(act), float(slope), ops._dt(x_cl), ops._stream())
         return y
@@ -274,11 +287,17 @@ class GeneratorFused:
         mel = mel if mel.is_contiguous() else mel.contiguous()
         att = g.input_proj.kernel_attention[1]
         K0, C0 = att.weight.shape[0], att.weight.shape[1]
-        chans = [u.mod.in_channels for u in self.ups]
-        # pooled channel sums handed from each producer to its consumer: dense [B][Cin] views of ONE buffer
-        nflat = sum(B * c for c in chans)
-        P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        # partial channel sums handed from each producer to its consumer (ODConv attention pooling, odconv.py:36-40,85): views of ONE
+        # buffer, each sized by its PRODUCER (slots x GEMM rows per sample); every element is written exactly once, nothing is
+        # accumulated with atomics, so two runs agree bit for bit
         has_cond = speaker_emb is not None or emotion_emb is not None
+        prods = [self.inp] + self.ups[:-1]
+        lens, T_ = [], mel.shape[2]
+        for j, pr in enumerate(prods):
+            lens.append(pr.pool_floats(B, T_, dt, N.ACT_NONE if j == 0 else N.ACT_LRELU, has_film=(j == 0 and has_cond)))
+            T_ = pr.out_len(T_)
+        nflat = sum(B * n for n in lens)
+        P = lambda t: None if t is None else c_void_p(t.data_ptr())
         fp = g.final_film.condition_projection
         F = g.final_film.feature_dim if has_cond else 0
         # one launch: attention of input_proj, the channels-last copy of the mel, the FiLM projection, the zero fill
@@ -290,7 +309,7 @@ class GeneratorFused:
         emo = None if emotion_emb is None else ops.cast(emotion_emb, dt).contiguous()
         rc = N.lib().mv_gen_prologue(P(mel), P(cache.get(att.weight, dt)), P(cache.get(att.bias, dt)), P(spk), P(emo),
                                      P(cache.get(fp.weight, dt)) if has_cond else None, P(cache.get(fp.bias, dt)) if has_cond else None,
-                                     P(alpha0), P(x), P(film_proj), P(flat), nflat, B, mel.shape[1], mel.shape[2], K0,
+                                     P(alpha0), P(x), P(film_proj), None, 0, B, mel.shape[1], mel.shape[2], K0,
                                      0 if spk is None else spk.shape[1], 0 if emo is None else emo.shape[1], fp.in_features, 2 * F,
                                      ops._dt(mel), ops._stream())
         if rc == -3:    # MV_ERR_UNSUPPORTED: a long utterance does not fit one workgroup's LDS - separate launches
@@ -300,14 +319,13 @@ class GeneratorFused:
             cond = g.final_film.condition(speaker_emb, emotion_emb)
             if cond is not None:
                 film_proj = ops.linear(ops.cast(cond, dt), cache.get(fp.weight, dt), cache.get(fp.bias, dt))
-            flat = torch.zeros(nflat, device=mel.device, dtype=torch.float32)
         else:
             N.check(rc, "mv_gen_prologue")
         cond = film_proj
         views, o = [], 0
-        for c in chans:
-            views.append(flat[o:o + B * c].view(B, c))
-            o += B * c
+        for n in lens:
+            views.append(flat[o:o + B * n].view(B, n))
+            o += B * n
         x = self.inp.forward_cl(x, cache, alpha=alpha0, film_proj=film_proj, film_F=F, pooled_out=views[0])
         if return_stages:
             st["film" if cond is not None else "input_proj"] = x

@@ -181,19 +181,26 @@ int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int*
  *   x [B][Tin][Cin], y [B][Tout][Cout] ("NTC").  `packed` = mv_odconv_cl_pack(kernels) (MFMA A-fragment order,
  *   mv_odconv_cl_packed_bytes bytes; kernels are [K,Cout,Cin,ks] (conv) or [K,Cin,Cout,ks] (transposed) in
  *   param_dtype).  bias [K][Cout] in `dtype` or NULL.
- *   alpha: fp32 [B][K] if already known; otherwise pooled_in (fp32 [B][Cin] = SUM over t of the layer input, as
- *   accumulated by the producing launch) with att_w [K][Cin], att_b [K] in `dtype`: alpha is then formed in the prologue.
+ *   alpha: fp32 [B][K] if already known; otherwise pooled_in = the producing launch's pooled_out (fp32 [B][pooled_in_count]:
+ *   per sample `slots` partial sums of every GEMM row, pooled_in_count = mv_odconv_cl_pool_floats(producer geometry); a dense
+ *   [B][Cin] buffer of channel sums is the special case pooled_in_count = Cin) with att_w [K][Cin], att_b [K] in `dtype`: alpha is
+ *   formed in the prologue by summing the partials in a fixed order (no atomics: two runs agree bit for bit).
  *   film_proj (optional): [B][2*film_F] in `dtype`; channels >= film_F pass through.
- *   pooled_out (optional): fp32 [B][Cout], must be zero on entry; receives SUM over t of the stored outputs.
+ *   pooled_out (optional): fp32 [B][mv_odconv_cl_pool_floats(...)], 16-byte aligned, need not be initialised; every element is
+ *   written exactly once: SUM over the columns of one workgroup of the stored outputs, per GEMM row (row % Cout = channel).
  *   Supported: Cin % 8 == 0, Cout % 8 == 0, GEMM rows (Cout, or stride*Cout) % 16 == 0; conv: stride 1; transposed:
  *   dilation 1 and ks % stride == 0.  Anything else returns MV_ERR_UNSUPPORTED (use the generic entry points). */
 size_t mv_odconv_cl_packed_bytes(int Cin, int Cout, int ks, int stride, int transposed, int K, int dtype);
 int mv_odconv_cl_pack(const void* kernels, int param_dtype, void* packed, int Cin, int Cout, int ks, int stride,
                       int transposed, int K, int dtype, void* stream);
 int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
-                     const void* att_w, const void* att_b, const void* film_proj, int film_F, void* y,
+                     int pooled_in_count, const void* att_w, const void* att_b, const void* film_proj, int film_F, void* y,
                      float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad,
                      int dil, int transposed, int K, int act, float slope, int dtype, void* stream);
+/* floats PER SAMPLE that the launch above writes to pooled_out (0 = unsupported geometry): slots x GEMM rows, where the slot
+ * count follows the kernel variant the dispatcher picks for this geometry. */
+size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                                int transposed, int K, int act, int has_film, int dtype);
 /* Generator prologue in one launch (one workgroup per sample): input_proj's attention alpha fp32 [B][K] (odconv.py:36-40),
  * mel [B][C][T] -> x_cl [B][T][C], the FiLM projection film_proj [B][F2] = W cond + b with cond = cat(spk [B][ds], emo [B][de])
  * truncated / zero-padded to cond_dim (grc_lora.py:82-105; film_proj NULL = no conditioning), and zeroing of zero_buf[0..zero_n)

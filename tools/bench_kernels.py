@@ -35,7 +35,7 @@ with torch.no_grad():
     prev = ops.nct_to_ntc(st["film"])
     for i, u in enumerate(fz.ups):
         pooled = prev.float().sum(dim=1).contiguous()
-        pout = torch.zeros(B, u.mod.out_channels, device="cuda")
+        pout = torch.empty(B, u.pool_floats(B, prev.shape[1], dt, N.ACT_LRELU), device="cuda")
         t = timeit(lambda: u.forward_cl(prev, Fn._cache, pooled_in=pooled, pooled_out=pout, act=N.ACT_LRELU))
         y = u.forward_cl(prev, Fn._cache, pooled_in=pooled, act=N.ACT_LRELU)
         byts = (prev.numel() + y.numel()) * es + u.mod.kernels.numel() * es
