@@ -53,6 +53,8 @@ template <> struct Mma<bf16> {
   }
   // packed weight fragment: base of this lane's 16 bytes in image 0 (images are `img_stride` bytes apart)
   static __device__ __forceinline__ V load_a(const char* p, int) { return load_b(p); }
+  // operand from a pre-split LDS tile (16-bit storage: the tile IS the operand; `plane` unused)
+  static __device__ __forceinline__ V load_bp(const void* p, int) { return load_b(p); }
   static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
     u32x4 u = {pack_bf16(x[0], x[1]), pack_bf16(x[2], x[3]), pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
     V r; r.v = __builtin_bit_cast(bf16x8_t, u); return r;
@@ -79,6 +81,8 @@ template <> struct Mma<f16> {
     V r; r.v = *reinterpret_cast<const f16x8_t*>(p); return r;
   }
   static __device__ __forceinline__ V load_a(const char* p, int) { return load_b(p); }
+  // operand from a pre-split LDS tile (16-bit storage: the tile IS the operand; `plane` unused)
+  static __device__ __forceinline__ V load_bp(const void* p, int) { return load_b(p); }
   static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
     u32x4 u = {pack_f16(x[0], x[1]), pack_f16(x[2], x[3]), pack_f16(y[0], y[1]), pack_f16(y[2], y[3])};
     V r; r.v = __builtin_bit_cast(f16x8_t, u); return r;
@@ -124,6 +128,20 @@ template <> struct Mma<float> {
     r.hi = *reinterpret_cast<const bf16x8_t*>(p);
     r.lo = *reinterpret_cast<const bf16x8_t*>(p + img_stride);
     return r;
+  }
+  // operand from a PRE-SPLIT LDS tile: hi plane at p, lo plane `plane` bytes further (both bf16).  The split happened once,
+  // when the tile was committed to LDS - load_b() above splits on every read, i.e. once per (tap, k-step, column tile).
+  static __device__ __forceinline__ V load_bp(const void* p, int plane) {
+    V r;
+    r.hi = *reinterpret_cast<const bf16x8_t*>(p);
+    r.lo = *reinterpret_cast<const bf16x8_t*>(reinterpret_cast<const char*>(p) + plane);
+    return r;
+  }
+  // 4 fp32 values -> 4 hi + 4 lo bf16 (8 bytes each)
+  static __device__ __forceinline__ void split4(const f32x4& a, u32x2& hi, u32x2& lo) {
+    hi[0] = pack_bf16(a[0], a[1]); hi[1] = pack_bf16(a[2], a[3]);
+    lo[0] = pack_bf16(a[0] - bf16_lo(hi[0]), a[1] - bf16_hi(hi[0]));
+    lo[1] = pack_bf16(a[2] - bf16_lo(hi[1]), a[3] - bf16_hi(hi[1]));
   }
   static __device__ __forceinline__ V from_acc(const f32x4& x, const f32x4& y) {
     const float f[8] = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};

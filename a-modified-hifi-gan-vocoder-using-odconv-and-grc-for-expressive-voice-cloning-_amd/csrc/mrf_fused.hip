@@ -189,9 +189,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
                                                           int Tn, int nwg, int nit, float eps) {
   using M = Mma<T>;
   using V = typename M::V;
-  constexpr int ES = M::ES;
+  constexpr int ES = M::ES;                           // storage element size in HBM
   constexpr int FS = M::NSETS * FRAG_BYTES;
-  constexpr int RS = MRF_C * ES + (ES == 2 ? 32 : 16); // padded LDS row stride: conflict-free ds_read_b128 operand reads
+  // LDS tile rows hold MFMA operands: 16-bit storage as stored; fp32 storage PRE-SPLIT into a hi and a lo bf16 plane per row
+  // (one split per element when the tile is committed, instead of one per operand read: 7 taps x 2 k-steps per column tile)
+  constexpr bool SPLIT = (ES == 4);
+  constexpr int LES = 2;                              // operand element size in LDS
+  constexpr int PLANE = MRF_C * LES;                  // byte offset of the lo plane inside a row (SPLIT)
+  constexpr int RS = (SPLIT ? 2 * PLANE : MRF_C * ES) + 32;   // padded LDS row stride: conflict-free ds_read_b128 operand reads
   constexpr int WBYTES = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
   constexpr int TW = NTW * 16;                        // time steps per wave and iteration
   constexpr int CH = MRF_C * ES / 16;                 // 16-byte chunks per row
@@ -241,7 +246,16 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     for (int i = 0; i < NLD; ++i) {
       const int idx = lane + 64 * i;
       const int r = idx / CH, ch = idx % CH;
-      if (idx < rows * CH) *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = pre[i];
+      if (idx < rows * CH) {
+        if constexpr (SPLIT) {
+          u32x2 hi, lo;
+          M::split4(__builtin_bit_cast(f32x4, pre[i]), hi, lo);
+          *reinterpret_cast<u32x2*>(xw + r * RS + ch * 8) = hi;
+          *reinterpret_cast<u32x2*>(xw + r * RS + PLANE + ch * 8) = lo;
+        } else {
+          *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = pre[i];
+        }
+      }
     }
   };
   issue(0);
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
   const float* b_conv = tab, *b_res = tab + 64, *b_fus = tab + 128;
   const float* g5 = tab + 192, *be5 = tab + 256, *g8 = tab + 320, *be8 = tab + 384;
-  const char* xcol = xw + (size_t)(col + H) * RS + 8 * g * ES;   // this lane's B-operand base
+  const char* xcol = xw + (size_t)(col + H) * RS + 8 * g * LES;  // this lane's B-operand base
   T* ob = out + (size_t)b * Tn * MRF_C;
 
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // statistics partials (passes 1, 2)
@@ -342,7 +356,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       auto ld_step = [&](int sidx, int set) {
         const int tap = sidx >> 1, ks = sidx & 1;
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) bfr[set][n] = M::load_b(xcol + (n * 16 + mrf_std_off(tap)) * RS + ks * 32 * ES);
+        for (int n = 0; n < NTW; ++n) bfr[set][n] = M::load_bp(xcol + (n * 16 + mrf_std_off(tap)) * RS + ks * 32 * LES, PLANE);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           if (mrf_std_frag(m, tap) >= 0) afr[set][m] = M::load_a(wl + (size_t)(mrf_std_frag(m, tap) * 2 + ks) * FS + lane * 16, FRAG_BYTES);
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
         // every operand of this k-step first (independent LDS reads in flight together), then the MFMAs
         V bf[NTW], af[4];
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16 + off) * RS + ks * 32 * ES);
+        for (int n = 0; n < NTW; ++n) bf[n] = M::load_bp(xcol + (n * 16 + off) * RS + ks * 32 * LES, PLANE);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int fo = meta.frag_of[m][tap];
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     for (int ks = 0; ks < 2; ++ks) {
       V bf[NTW], af[4];
 #pragma unroll
-      for (int n = 0; n < NTW; ++n) bf[n] = M::load_b(xcol + (n * 16) * RS + ks * 32 * ES);
+      for (int n = 0; n < NTW; ++n) bf[n] = M::load_bp(xcol + (n * 16) * RS + ks * 32 * LES, PLANE);
 #pragma unroll
       for (int m = 0; m < 4; ++m) af[m] = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + m * 2 + ks) * FS + lane * 16, FRAG_BYTES);
 #pragma unroll
@@ -478,9 +492,17 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
           const int t = t0 + n * 16 + col;
-          char* cell = xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES;
+          char* rowp = xw + (size_t)(n * 16 + col + H) * RS;
           float xr[4], o[4];
-          M::load4(cell, xr);
+          if constexpr (SPLIT) {
+            float lo4[4];
+            Mma<bf16>::load4(rowp + (16 * m + 4 * g) * LES, xr);
+            Mma<bf16>::load4(rowp + PLANE + (16 * m + 4 * g) * LES, lo4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xr[r] += lo4[r];
+          } else {
+            M::load4(rowp + (16 * m + 4 * g) * ES, xr);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sc = rs * ga[r];
@@ -488,8 +510,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
             if (HAS_MASK) w = (t < Tn && mask[((size_t)b * Tn + t) * MRF_C + 16 * m + 4 * g + r]) ? w * mask_scale : 0.f;
             o[r] = w + xr[r];
           }
-          M::store4(cell, o);
+          if constexpr (SPLIT) {
+            // the fp32 output row overlaps the hi/lo planes of OTHER channels of the same row: keep the results in registers
+            // until every residual read of the tile has been issued (second loop below)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[m][n][r] = o[r];
+          } else {
+            M::store4(rowp + (16 * m + 4 * g) * ES, o);    // same bytes this lane has just read
+          }
         }
+      }
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NTW; ++n) {
+            const float o[4] = {f[m][n][0], f[m][n][1], f[m][n][2], f[m][n][3]};
+            M::store4(xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES, o);
+          }
       }
     };
     if (mask) stage4(std::true_type{}); else stage4(std::false_type{});
@@ -563,7 +601,7 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
                       const uint8_t* mask, float mask_scale, int B, int Tn, float eps, hipStream_t stream) {
   using M = Mma<T>;
   constexpr int FS = M::NSETS * FRAG_BYTES;
-  constexpr int RS = MRF_C * M::ES + (M::ES == 2 ? 32 : 16);
+  constexpr int RS = (M::ES == 4 ? 2 * MRF_C * 2 : MRF_C * M::ES) + 32;   // as in the kernel
   int nwg, nit;
   mrf_geometry(B, Tn, NWAVES * NTW * 16, &nwg, &nit);
   const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
@@ -625,8 +663,8 @@ extern "C" size_t mv_mrf_packed_bytes(int dtype) {
   }
 }
 
-// tile geometry per storage type: bf16/f16: 8 waves x 64 steps; fp32 (bf16x3 operands, 2x LDS): 4 waves x 32 steps
-static inline int mrf_tile_t(int dtype) { return dtype == MV_F32 ? 4 * 2 * 16 : 8 * 4 * 16; }
+// tile geometry per storage type: bf16/f16: 8 waves x 64 steps; fp32 (split operands, 2x LDS): 8 x 16 or 4 x 32 steps
+static inline int mrf_tile_t(int dtype) { return dtype == MV_F32 ? 8 * 1 * 16 : 8 * 4 * 16; }
 
 extern "C" size_t mv_mrf_workspace_bytes(int B, int T_, int dtype) {
   const int ntiles = cdiv(T_, mrf_tile_t(dtype));   // upper bound on workgroups per sample
@@ -668,7 +706,13 @@ extern "C" int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed,
   if (!mrf_make_meta(dilations, &meta)) return MV_ERR_UNSUPPORTED;
   int rc;
   switch (dtype) {
-    case MV_F32: rc = mrf_launch<float, 4, 2>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
+    case MV_F32:
+      // 8 waves x 16 steps (two waves per SIMD overlap each other's LDS / VALU phases: 150 -> 134 us per block at C2); wide
+      // dilations (halo > 5) do not fit 160 KB next to the hi+lo weight images: 4 waves x 32 steps, same 128-step workgroup tile
+      rc = mrf_launch<float, 8, 1>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream);
+      if (rc == MV_ERR_UNSUPPORTED)
+        rc = mrf_launch<float, 4, 2>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream);
+      break;
     case MV_BF16: rc = mrf_launch<bf16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
     case MV_F16: rc = mrf_launch<f16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
     default: return MV_ERR_DTYPE;

@@ -92,10 +92,15 @@ class ModifiedHiFiGANVocoder(nn.Module):
 class VocoderTrainer:
     """complete_vocoder.py:186-248.  Optimizers: anything with zero_grad()/step(); `FlatAdamW` (optim.py) is the native
     one and is what `default_optimizers` builds (lr 2e-4, betas (0.8, 0.99), wd 1e-4: configs/train_config.yaml:54-72).
-    `grad_sync` (parallel.GradSynchronizer) adds the data-parallel all-reduce."""
+
+    Data parallel (one process per GPU, torch.distributed initialised): `grad_sync="overlap"` (the default when the world
+    size is > 1) reduces each optimizer's gradient buckets UNDER its backward (parallel.OverlappedGradSync); a
+    `parallel.GradSynchronizer` instance reduces the flat buffer after the backward instead; `grad_sync=False` never reduces.
+    `train_step` returns host floats like the reference (:229-233); `return_tensors=True` keeps device tensors and skips the
+    device synchronisation a `.item()` costs."""
 
     def __init__(self, vocoder: ModifiedHiFiGANVocoder, generator_optimizer=None, discriminator_optimizer=None,
-                 device=None, mel_mode: str = "stft", grad_sync=None):
+                 device=None, mel_mode: str = "stft", grad_sync=None, bucket_mib: int = 8):
         device = device or torch.device("cuda")
         self.vocoder = vocoder.to(device)
         self.device = device
@@ -104,7 +109,12 @@ class VocoderTrainer:
         self.generator_optimizer = generator_optimizer
         self.discriminator_optimizer = discriminator_optimizer
         self.mel_mode = mel_mode
+        if grad_sync is None:
+            import torch.distributed as dist
+            grad_sync = "overlap" if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else False
         self.grad_sync = grad_sync
+        self.bucket_mib = bucket_mib
+        self._overlap = {}
         self._d_params = list(self.vocoder.discriminators.parameters())
 
     @staticmethod
@@ -115,21 +125,49 @@ class VocoderTrainer:
         d = FlatAdamW(vocoder.discriminators.parameters(), lr=lr, betas=betas, weight_decay=weight_decay)
         return g, d
 
-    def _step(self, opt):
+    def overlap_sync(self, opt):
+        """The OverlappedGradSync of a FlatAdamW optimizer (created on first use), or None when overlap is off."""
+        if self.grad_sync != "overlap" and self.grad_sync is not True:
+            return None
+        ov = self._overlap.get(id(opt))
+        if ov is None:
+            from .parallel import OverlappedGradSync
+            ov = self._overlap[id(opt)] = OverlappedGradSync(opt, bucket_mib=self.bucket_mib)
+        return ov
+
+    def _backward_and_step(self, loss, opt):
+        """loss.backward() + (data-parallel gradient mean) + optimizer step (complete_vocoder.py:217-218, :225-226)."""
         from .optim import FlatAdamW
         if isinstance(opt, FlatAdamW):
-            flat = opt.gather_grads()
-            scale = 1.0
-            if self.grad_sync is not None:
-                self.grad_sync.start(flat)
-                scale = self.grad_sync.finish()
+            ov = self.overlap_sync(opt)
+            if ov is not None:
+                ov.begin()                          # buckets reduce while autograd is still producing the other gradients
+                loss.backward()
+                scale = ov.finish()
+            else:
+                loss.backward()
+                flat = opt.gather_grads()
+                scale = 1.0
+                if self.grad_sync:
+                    self.grad_sync.start(flat)
+                    scale = self.grad_sync.finish()
             opt.step(grad_scale=scale, gathered=True)
             from . import disc_fused
             disc_fused._packs.refresh_owned(opt)     # all conv packs of the stepped module in one launch
         else:
+            loss.backward()
+            if self.grad_sync:
+                import torch.distributed as dist
+                w = dist.get_world_size()
+                for g in opt.param_groups:
+                    for p in g["params"]:
+                        if p.grad is not None:
+                            dist.all_reduce(p.grad)
+                            p.grad.div_(w)
             opt.step()
 
-    def train_step(self, mel_spectrogram, real_audio, speaker_embedding=None, emotion_embedding=None) -> Dict[str, float]:
+    def train_step(self, mel_spectrogram, real_audio, speaker_embedding=None, emotion_embedding=None,
+                   return_tensors: bool = False) -> Dict[str, float]:
         mel_spectrogram = mel_spectrogram.to(self.device)
         real_audio = real_audio.to(self.device)
         out = self.vocoder(mel_spectrogram, speaker_embedding, emotion_embedding)
@@ -137,8 +175,7 @@ class VocoderTrainer:
         # discriminator step on the detached fake
         self.discriminator_optimizer.zero_grad()
         d_losses = self.vocoder.compute_discriminator_losses(real_audio, fake_audio.detach())
-        d_losses["total_loss"].backward()
-        self._step(self.discriminator_optimizer)
+        self._backward_and_step(d_losses["total_loss"], self.discriminator_optimizer)
         # generator step: discriminators re-evaluated after their update; their own weight gradients are not needed
         # (the reference accumulates and then zeroes them at the next D step)
         self.generator_optimizer.zero_grad()
@@ -150,19 +187,19 @@ class VocoderTrainer:
                 g_losses = self.vocoder.compute_generator_losses(real_audio, fake_audio, target, None)
             else:   # the reference's placeholder: generated_mel = mel_spectrogram -> the term is zero
                 g_losses = self.vocoder.compute_generator_losses(real_audio, fake_audio, mel_spectrogram, mel_spectrogram)
-            g_losses["total_loss"].backward()
+            self._backward_and_step(g_losses["total_loss"], self.generator_optimizer)
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
-        self._step(self.generator_optimizer)
         self.last_losses = (g_losses, d_losses)
-        return {"generator_loss": g_losses["total_loss"], "discriminator_loss": d_losses["total_loss"],
-                "mel_loss": g_losses["mel_loss"]}
+        res = {"generator_loss": g_losses["total_loss"], "discriminator_loss": d_losses["total_loss"],
+               "mel_loss": g_losses["mel_loss"]}
+        return res if return_tensors else self.to_floats(res)       # complete_vocoder.py:229-233 returns .item() floats
 
     @staticmethod
     def to_floats(losses):
-        """Host read-back of a loss dict (kept out of train_step so a step does not force a device sync)."""
-        return {k: float(v.detach()) for k, v in losses.items()}
+        """Host read-back of a loss dict (one device synchronisation)."""
+        return {k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in losses.items()}
 
     def save_checkpoint(self, path: str):
         torch.save({"vocoder_state_dict": self.vocoder.state_dict(),

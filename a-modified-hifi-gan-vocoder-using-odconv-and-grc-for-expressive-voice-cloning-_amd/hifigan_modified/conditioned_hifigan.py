@@ -84,13 +84,20 @@ class ConditionedHiFiGAN(nn.Module):
 class HiFiGANTrainer:
     """conditioned_hifigan.py:210-299.  One optimizer over G + MPD + MSD (`FlatAdamW`, lr 2e-4, torch AdamW defaults)."""
 
-    def __init__(self, model, learning_rate=2e-4, device="cuda", sample_rate=22050, n_fft=1024, grad_sync=None):
+    def __init__(self, model, learning_rate=2e-4, device="cuda", sample_rate=22050, n_fft=1024, grad_sync=None, bucket_mib=8):
         from .optim import FlatAdamW
         self.model = model
         self.device = device
         g = model.generator.generator
         self.optimizer = FlatAdamW(model.parameters(), lr=learning_rate, exclude=list(g.unused_parameters()))
+        if grad_sync is None:       # data parallel by default when torch.distributed is up: buckets reduce under the backward
+            import torch.distributed as dist
+            grad_sync = "overlap" if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else False
         self.grad_sync = grad_sync
+        self._overlap = None
+        if grad_sync == "overlap" or grad_sync is True:
+            from .parallel import OverlappedGradSync
+            self._overlap = OverlappedGradSync(self.optimizer, bucket_mib=bucket_mib)
         hop = 1
         for f in g.upsample_factors:
             hop *= f
@@ -128,12 +135,17 @@ class HiFiGANTrainer:
         self.optimizer.zero_grad()
         fake_audio = self.model(mel_input, speaker_emb=speaker_emb, emotion_emb=emotion_emb)
         total, breakdown = self.compute_losses(real_audio, fake_audio, mel_input)
-        total.backward()
-        flat = self.optimizer.gather_grads()
-        scale = 1.0
-        if self.grad_sync is not None:
-            self.grad_sync.start(flat)
-            scale = self.grad_sync.finish()
+        if self._overlap is not None:
+            self._overlap.begin()
+            total.backward()
+            scale = self._overlap.finish()
+        else:
+            total.backward()
+            flat = self.optimizer.gather_grads()
+            scale = 1.0
+            if self.grad_sync:
+                self.grad_sync.start(flat)
+                scale = self.grad_sync.finish()
         self.optimizer.step(grad_scale=scale, gathered=True)
         return total.item(), breakdown
 

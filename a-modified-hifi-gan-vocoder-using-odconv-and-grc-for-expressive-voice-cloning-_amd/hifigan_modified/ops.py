@@ -589,9 +589,22 @@ def scale_(x, factor=1.0, factor_dev=None):
 
 def mel_loss(wave, fb, target=None, n_fft=1024, hop=256, clampv=1e-5, weight=1.0, backward=False, want_mel=False,
              kind=0):
+    # the C entry point receives no tensor sizes for target / fb: a wrong shape would be an out-of-bounds device read or a
+    # silently misaligned loss, where the reference's F.l1_loss / F.mse_loss raise - so raise here
+    if wave.dim() != 3 or wave.shape[1] != 1:
+        raise ValueError(f"mel_loss: wave must be [B, 1, T], got {tuple(wave.shape)}")
     wave = _c(wave)
     B, _, T = wave.shape
+    if T % hop != 0:
+        raise ValueError(f"mel_loss: T = {T} is not a multiple of hop = {hop}")
+    if fb.dim() != 2 or fb.shape[1] != n_fft // 2 + 1 or fb.dtype != torch.float32:
+        raise ValueError(f"mel_loss: filterbank must be fp32 [n_mels, {n_fft // 2 + 1}] for n_fft = {n_fft}, got {tuple(fb.shape)} {fb.dtype}")
+    fb = _c(fb)
     n_mels = fb.shape[0]
+    if target is not None and tuple(target.shape) != (B, n_mels, T // hop):
+        raise ValueError(f"mel_loss: target must be [B, n_mels, T/hop] = {(B, n_mels, T // hop)}, got {tuple(target.shape)}")
+    if (backward or not want_mel) and target is None:
+        raise ValueError("mel_loss: a loss (or its gradient) needs a target mel")
     acc = _scalars.take(wave.device)
     mel = _f32(B, n_mels, T // hop, device=wave.device) if want_mel else None
     gwave = torch.zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None

@@ -22,7 +22,10 @@ _DESC = np.dtype([("src", np.uint64), ("dst_off", np.int64), ("n", np.int64), ("
 class FlatAdamW:
     def __init__(self, params, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, exclude=()):
         excl = {id(p) for p in exclude}
-        self.params = [p for p in params if p.requires_grad and id(p) not in excl]
+        params = list(params)
+        keep = [i for i, p in enumerate(params) if p.requires_grad and id(p) not in excl]
+        self.torch_index = keep                  # position of each arena parameter in the list a torch.optim optimizer would enumerate
+        self.params = [params[i] for i in keep]
         if not self.params:
             raise ValueError("FlatAdamW: no trainable parameters")
         dev = self.params[0].device
@@ -54,6 +57,7 @@ class FlatAdamW:
         self._descs["dst_off"] = self.offsets
         self._descs["n"] = [p.numel() for p in self.params]
         self._max_len = int(self._descs["n"].max())
+        self._has_grad = None        # per parameter, set by the gathers of the current step (None = every parameter)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -62,6 +66,7 @@ class FlatAdamW:
     def gather_grads(self):
         """param.grad tensors (fresh per backward) -> flat fp32 buffer; missing grads contribute zeros."""
         d = self._descs
+        self._has_grad = [p.grad is not None for p in self.params]
         for i, p in enumerate(self.params):
             g = p.grad
             if g is None:
@@ -77,14 +82,54 @@ class FlatAdamW:
         self._table = table   # keep alive until the launch has consumed it
         return self.flat_g
 
+    def gather_range(self, i0, i1):
+        """Gather the gradients of parameters i0..i1-1 only (one launch): the per-bucket form used by
+        parallel.OverlappedGradSync while the backward is still running.  Missing gradients contribute zeros."""
+        d = self._descs[i0:i1].copy()
+        if self._has_grad is None or len(self._has_grad) != len(self.params):
+            self._has_grad = [True] * len(self.params)
+        for j, p in enumerate(self.params[i0:i1]):
+            g = p.grad
+            self._has_grad[i0 + j] = g is not None
+            if g is None:
+                d["src"][j], d["dtype"][j] = 0, 0
+            else:
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                    p.grad = g
+                d["src"][j], d["dtype"][j] = g.data_ptr(), ops._DT[g.dtype]
+        table = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.flat_g.device, non_blocking=True)
+        N.call("mv_multi_gather", c_void_p(table.data_ptr()), i1 - i0, int(d["n"].max()),
+               c_void_p(self.flat_g.data_ptr()), ops._stream())
+        self._tables = getattr(self, "_tables", [])[-64:] + [table]   # keep alive until the launches have consumed them
+
     def step(self, grad_scale=1.0, gathered=False):
         if not gathered:
             self.gather_grads()
         self.step_count += 1
-        N.call("mv_adamw_flat", c_void_p(self.flat_p.data_ptr()), c_void_p(self.flat_g.data_ptr()),
-               c_void_p(self.exp_avg.data_ptr()), c_void_p(self.exp_avg_sq.data_ptr()), self.numel, float(self.lr),
-               float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-               int(self.step_count), float(grad_scale), ops._stream())
+        # torch.optim.AdamW leaves a parameter whose .grad is None untouched (no weight decay, no moment decay): update only the
+        # runs of parameters that received a gradient this step - one launch when all did, which is the usual case
+        hg = self._has_grad
+        runs = [(0, self.numel)]
+        if hg is not None and not all(hg):
+            runs, i, n = [], 0, len(self.params)
+            while i < n:
+                if hg[i]:
+                    j = i
+                    while j + 1 < n and hg[j + 1]:
+                        j += 1
+                    end = self.numel if j == n - 1 else self.offsets[j + 1]
+                    runs.append((self.offsets[i], end - self.offsets[i]))
+                    i = j + 1
+                else:
+                    i += 1
+        for off, cnt in runs:
+            b = 4 * off
+            N.call("mv_adamw_flat", c_void_p(self.flat_p.data_ptr() + b), c_void_p(self.flat_g.data_ptr() + b),
+                   c_void_p(self.exp_avg.data_ptr() + b), c_void_p(self.exp_avg_sq.data_ptr() + b), cnt, float(self.lr),
+                   float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                   int(self.step_count), float(grad_scale), ops._stream())
+        self._has_grad = None
         ops.bump_param_epoch(self)       # in-place arena update: cached casts / packed weights of THESE parameters must refresh
         self._refresh_shadows()
 
@@ -118,11 +163,45 @@ class FlatAdamW:
         o = self.offsets[i]
         return self._shadows[dtype][o:o + p.numel()].view(p.shape)
 
+    def torch_state_dict(self):
+        """The same state in torch.optim.AdamW's layout (what the reference's load path expects)."""
+        state = {}
+        for p, o, ti in zip(self.params, self.offsets, self.torch_index):
+            state[ti] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+                         "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
+        n_all = (max(self.torch_index) + 1) if self.torch_index else 0
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(n_all))}
+        return {"state": state, "param_groups": [group]}
+
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
 
     def load_state_dict(self, sd):
+        """Accepts this class's flat layout, or a torch.optim.AdamW state_dict ({'state': {i: {step, exp_avg, exp_avg_sq}},
+        'param_groups': [...]}, the 'optimizer_state_dict' of a reference checkpoint: conditioned_hifigan.py:292-299) built over
+        the same parameter list: entry i belongs to the i-th parameter the torch optimizer enumerated (self.torch_index)."""
+        if "state" in sd and "param_groups" in sd:
+            g0 = sd["param_groups"][0]
+            self.lr, self.betas, self.eps = g0.get("lr", self.lr), tuple(g0.get("betas", self.betas)), g0.get("eps", self.eps)
+            self.weight_decay = g0.get("weight_decay", self.weight_decay)
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            step = 0
+            with torch.no_grad():
+                for p, o, ti in zip(self.params, self.offsets, self.torch_index):
+                    st = sd["state"].get(ti, sd["state"].get(str(ti)))
+                    if st is None:
+                        continue
+                    if st["exp_avg"].numel() != p.numel():
+                        raise ValueError(f"optimizer state {ti}: {tuple(st['exp_avg'].shape)} does not fit parameter {tuple(p.shape)}")
+                    self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+                    step = max(step, int(st["step"]))
+            self.step_count = step
+            return
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

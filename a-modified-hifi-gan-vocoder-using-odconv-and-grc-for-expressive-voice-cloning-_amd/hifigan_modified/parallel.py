@@ -2,9 +2,15 @@
 
 Samples are independent in every op of the path (GroupNorm and the ODConv attention are per-sample; there is no
 BatchNorm), so the only exchange is one all-reduce(mean) of gradients per optimizer step.  `FlatAdamW` already holds the
-gradients of a parameter group in one flat fp32 buffer; `GradSynchronizer` cuts it into buckets (default 32 MiB: the
-33.6 MB `upsample_layers.0.0.kernels` is its own bucket) and issues asynchronous all-reduces on them.  xGMI is
-point-to-point (7 links per GPU), so a few large buckets are preferred over many small ones; RCCL picks ring/direct.
+gradients of a parameter group in one flat fp32 buffer.  Two ways to reduce it:
+
+* `GradSynchronizer` - after the backward: the whole buffer, cut into fixed-size buckets, asynchronous all-reduces.
+* `OverlappedGradSync` - UNDER the backward: the arena is cut into buckets of whole parameters; a post-accumulate-grad hook per
+  parameter counts arrivals, and the moment a bucket's last gradient exists that bucket is gathered into the flat buffer and its
+  all-reduce is enqueued (RCCL runs it on its own stream, ordered after the gather by an event), while autograd keeps producing
+  the remaining gradients on the compute stream.  The discriminator buckets thus reduce under the rest of the discriminator
+  backward, the generator buckets under the rest of the generator backward.  xGMI is point-to-point
+  (7 links per GPU), so buckets stay large (default 8 MiB; `upsample_layers.0.0.kernels`, 33.6 MB, is a bucket of its own).
 """
 from __future__ import annotations
 
@@ -68,3 +74,95 @@ class GradSynchronizer:
             w.wait()
         self.pending = []
         return 1.0 / self.world
+
+
+class OverlappedGradSync:
+    """Gradient all-reduce overlapped with the backward of ONE FlatAdamW parameter group (see the module docstring).
+
+    usage per step:   sync.begin(); loss.backward(); scale = sync.finish(); opt.step(grad_scale=scale, gathered=True)
+    `finish()` gathers and reduces whatever did not complete during the backward (parameters without a gradient count as
+    zeros, exactly like FlatAdamW.gather_grads), waits for every bucket and returns 1/world.  With world size 1 it degrades to
+    one gather.  `exposed_ms` accumulates the time the compute stream spent waiting in finish() (what the overlap did not hide)."""
+
+    def __init__(self, opt, bucket_mib=8, timing=False):
+        self.opt = opt
+        be = max(1, bucket_mib * (1 << 20) // 4)
+        # buckets = runs of whole parameters in arena order, closed once they reach the bucket size
+        self.buckets, i0, acc = [], 0, 0
+        for i, p in enumerate(opt.params):
+            acc += p.numel()
+            if acc >= be or i == len(opt.params) - 1:
+                o0 = opt.offsets[i0]
+                o1 = opt.numel if i == len(opt.params) - 1 else opt.offsets[i + 1]
+                self.buckets.append((i0, i + 1, o0, o1 - o0))
+                i0, acc = i + 1, 0
+        self._bucket_of = {}
+        for b, (a, e, _, _) in enumerate(self.buckets):
+            for i in range(a, e):
+                self._bucket_of[i] = b
+        self._need = [e - a for a, e, _, _ in self.buckets]
+        self._have = [0] * len(self.buckets)
+        self._launched = [True] * len(self.buckets)     # nothing armed until begin()
+        self._works = []
+        self._armed = False
+        self.timing = timing
+        self.exposed_ms = 0.0
+        self.reduced_bytes = 0
+        self._ev = []
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    @property
+    def world(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def _make_hook(self, i):
+        def hook(_p):
+            if not self._armed:
+                return
+            b = self._bucket_of[i]
+            self._have[b] += 1
+            if self._have[b] == self._need[b] and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def begin(self):
+        """Arm the hooks for the next backward of this parameter group."""
+        self._have = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self._armed = True
+
+    def _launch(self, b):
+        a, e, off, n = self.buckets[b]
+        self.opt.gather_range(a, e)
+        self._launched[b] = True
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.opt.flat_g[off:off + n], op=dist.ReduceOp.SUM, async_op=True))
+            self.reduced_bytes += 4 * n
+
+    def finish(self):
+        self._armed = False
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        if self._works:
+            if self.timing and torch.cuda.is_available():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for w in self._works:
+                    w.wait()
+                e1.record()
+                self._ev.append((e0, e1))
+            else:
+                for w in self._works:
+                    w.wait()
+        self._works = []
+        return 1.0 / self.world
+
+    def collect_timing(self):
+        """Sum the recorded waits (call after a device synchronize)."""
+        for e0, e1 in self._ev:
+            self.exposed_ms += e0.elapsed_time(e1)
+        self._ev = []
+        return self.exposed_ms

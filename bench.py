@@ -447,11 +447,11 @@ def main():
         tspk, temo = torch.randn(B, 192, device=dev).to(tdtype), torch.randn(B, 384, device=dev).to(tdtype)
         torch.manual_seed(2 + rank)      # dropout stream of this rank
         for _ in range(args.train_warmup):
-            losses = trainer.train_step(tmel, treal, tspk, temo)
+            losses = trainer.train_step(tmel, treal, tspk, temo, return_tensors=True)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
-            losses = trainer.train_step(tmel, treal, tspk, temo)
+            losses = trainer.train_step(tmel, treal, tspk, temo, return_tensors=True)
         sync_all()
         tel = time.perf_counter() - t0
         if world > 1:

@@ -65,3 +65,75 @@ def test_grad_allreduce_gloo_world2():
     assert nb0 == nb1 == 3 and sc0 == sc1 == 0.5
     # mean of rank values: (1+2)/2 = 1.5 everywhere except every 7th element: (0+10)/2 = 5
     assert head0[1] == 1.5 and head0[0] == 5.0 and head0[7] == 5.0
+
+
+class _CpuArena:
+    """The slice of FlatAdamW that OverlappedGradSync uses (params, offsets, numel, flat_g, gather_range), in plain torch on the
+    CPU: lets the bucket / hook / collective logic run under gloo without a GPU."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 7) // 8 * 8
+        self.numel = off
+        self.flat_g = torch.zeros(off)
+        self.gathered = []
+
+    def gather_range(self, i0, i1):
+        self.gathered.append((i0, i1))
+        for p, o in zip(self.params[i0:i1], self.offsets[i0:i1]):
+            self.flat_g[o:o + p.numel()] = 0 if p.grad is None else p.grad.reshape(-1)
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from conftest import PKG, ROOT  # noqa: F401
+    from hifigan_modified.parallel import OverlappedGradSync, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(0)                                   # same weights on both ranks
+    net = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(),
+                              torch.nn.Linear(300, 8))
+    frozen = torch.nn.Parameter(torch.randn(5))            # a parameter that never gets a gradient (zeros in the flat buffer)
+    arena = _CpuArena(list(net.parameters()) + [frozen])
+    sync = OverlappedGradSync(arena, bucket_mib=0)         # bucket size 1 element -> every parameter is its own bucket
+    sync2 = OverlappedGradSync(_CpuArena(list(net.parameters())), bucket_mib=1)   # 262144 elements: one bucket for this net
+    torch.manual_seed(10 + rank)                           # different data per rank
+    x, y = torch.randn(16, 64), torch.randn(16, 8)
+    order = []
+    orig = sync._launch
+    sync._launch = lambda b: (order.append(b), orig(b))[1]
+    sync.begin()
+    ((net(x) - y) ** 2).mean().backward()
+    launched_in_backward = list(order)
+    scale = sync.finish()
+    local = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    flat = torch.cat([arena.flat_g[o:o + p.numel()] for p, o in zip(arena.params, arena.offsets)]) * scale
+    q.put((rank, local.tolist(), flat.tolist(), launched_in_backward, order, len(sync.buckets), len(sync2.buckets), scale))
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_allreduce_gloo_world2():
+    """OverlappedGradSync: buckets are launched from grad-ready hooks DURING the backward (last layer first), the rest in
+    finish(); the reduced buffer is the mean of the two ranks' gradients; a gradient-less parameter contributes zeros."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, f0, inb0, ord0, nb, nb2, sc), (_, l1, f1, inb1, ord1, _, _, _) = res
+    assert sc == 0.5 and nb == 7 and nb2 == 1
+    assert f0 == f1                                              # identical on both ranks
+    mean = [(a + b) / 2 for a, b in zip(l0, l1)]
+    n = len(mean)
+    assert max(abs(a - b) for a, b in zip(f0[:n], mean)) < 1e-6   # = mean of the local gradients
+    assert all(v == 0.0 for v in f0[n:])                          # the frozen parameter
+    # the six trainable parameters were reduced from hooks, output layer first; only the frozen one waited for finish()
+    assert inb0 == inb1 == [5, 4, 3, 2, 1, 0] and ord0[-1] == 6

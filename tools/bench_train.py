@@ -16,13 +16,13 @@ mel = torch.randn(B, 80, Tm, device="cuda").to(dt)
 real = torch.randn(B, 1, Tm * 256, device="cuda").clamp(-1, 1).to(dt)
 spk, emo = torch.randn(B, 192, device="cuda").to(dt), torch.randn(B, 384, device="cuda").to(dt)
 for i in range(2):
-    out = tr.train_step(mel, real, spk, emo)
+    out = tr.train_step(mel, real, spk, emo, return_tensors=True)
 torch.cuda.synchronize()
 print({k: float(v) for k, v in out.items()})
 t0 = time.perf_counter()
 n = 3
 for i in range(n):
-    tr.train_step(mel, real, spk, emo)
+    tr.train_step(mel, real, spk, emo, return_tensors=True)
 torch.cuda.synchronize()
 dtm = (time.perf_counter() - t0) / n
 print(f"B={B} T={Tm*256} {dt}: {dtm*1e3:.1f} ms/step  -> {B*Tm*256/dtm:,.0f} samples/s")
