@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: mel-frames/s vocoded by the V1 + ODConv + GRC-LoRA generator (BASELINE.json
-configs[1]: B=32 clips x 32 mel frames -> 8192 samples, 80-mel, 22.05 kHz, bf16, inference), one
-process per GPU.  Prints ONE JSON line on rank 0 (contract in the task description).
+configs[1]: B=32 clips x 32 mel frames -> 8192 samples, 80-mel, 22.05 kHz, inference), one process per
+GPU.  Prints ONE JSON line on rank 0 (contract in the task description).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype fp32|bf16|fp16] [--no-cpu-baseline]
+
+`--gpus N` (N > 1) without a torchrun environment starts `python -m torch.distributed.run` with N ranks as a CHILD
+process before anything touches the GPU and relays its output; under torchrun (WORLD_SIZE set) each rank runs in place.
+
+PRECISION.  north_star asks for <= 1e-3 relative L2 on the waveform.  tools/error_budget.py (a CPU simulation of every
+rounding the 16-bit pipeline performs) shows that no pipeline with single 16-bit MFMA operands can meet that on this
+network: fp16 everywhere lands at 1.5e-3 (22 kHz) / 4.8e-3 (48 kHz) from rounding alone, bf16 at 1.2e-2.  The headline
+therefore runs the fastest mode that does meet it: fp32 storage with every MFMA operand split into a hi and a lo bf16
+part (three products per MAC, fp32 accumulate; `--dtype fp32`).  The 16-bit storage modes are timed beside it under
+"modes", each with its measured parity and `"parity_ok": false`.
 
 A "step" is one generator forward over one batch of synthetic mels already resident in HBM.
 Inference shards by minibatch with no data-path collective (replicas only -> weak scaling).
 `roofline` is measured live with HIP events on the launch stream around the MRF ("ResBlock") stage,
-the largest HBM mover of the path (256 B per output sample = 67.1 MB per block per
-batch of 32 in bf16).  `cpu_baseline` times the CPU oracle (reference K-loop formulation, fp32) on
-the host cores of the same box for a bounded sample.
+the largest HBM mover of the path (64 channels in + 64 out per output sample = 134.2 MB
+per block per batch of 32 in fp32 storage, 67.1 MB in 16-bit storage); `roofline.traffic` comes from the committed PMC
+summary (profiles/, written by tools/profile_summary.py) and is null when that summary was taken from other kernel sources.
+`cpu_baseline` times the CPU oracle (reference K-loop formulation, fp32) on the host cores of the same box for a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -86,11 +99,13 @@ def cpu_baseline(sd, n_threads, budget_s=24.0, checks=None, embed_check=None, ch
                 n += 1
             out["config_v3_plain"] = {"value": round(344 * n / (time.perf_counter() - t0), 1), "unit": "mel-frames/s", "cores": best["cores"],
                                       "kind": "port", "sample": "%d forwards of B=1 x 344 frames, fp32" % n}
-    if check48 is not None:          # 48 kHz leg: one B=2 oracle forward as its checker
+    if check48 is not None:          # 48 kHz leg: one B=2 oracle forward as the checker of every storage mode timed there
         w48, (mm, ss, ee), sd48 = check48
         torch.set_num_threads(best["cores"])
         with torch.no_grad():
-            out.setdefault("parity", {})["config_48k_fp16"] = O.rel_l2(w48, O.generator_forward(mm, sd48, "", ss, ee, upsample_factors=(8, 8, 4, 2)))
+            ref48 = O.generator_forward(mm, sd48, "", ss, ee, upsample_factors=(8, 8, 4, 2))
+            for tag, w in w48.items():
+                out.setdefault("parity", {})["config_48k_" + tag] = O.rel_l2(w, ref48)
     if embed_check is not None:      # conditioning producers: oracle/embed_oracle.py as checker and as the CPU figure (bounded: <= 3 s)
         from oracle import embed_oracle as E
         esd, emel, spk_gpu, emo_gpu = embed_check
@@ -143,27 +158,94 @@ def graph_time_ms(run, inner=20, outer=5):
     return min(t_graph, t_eager)
 
 
+PARITY_TOL = 1e-3           # north_star: waveform rel-L2 vs the reference CPU path
+DT = {"bf16": "bfloat16", "fp16": "float16", "fp32": "float32"}
+
+
+def spawn_ranks(n):
+    """`bench.py --gpus N` outside torchrun: run the N ranks as a child `torch.distributed.run` (started before this process has
+    made any GPU call - a process that initialised the GPU must never exec) and exit with its code."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(kernel_substr, dtype_tag):
+    """HBM bytes per launch group from the committed PMC summary (profiles/*_pmc_traffic.json, tools/profile_summary.py), or None
+    when no summary matches this dtype or the kernel source has changed since it was taken (sha1 recorded in the summary)."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not f.endswith("_pmc_traffic.json"):
+            continue
+        try:
+            j = json.load(open(os.path.join(pdir, f)))
+        except (OSError, ValueError):
+            continue
+        if j.get("dtype") != dtype_tag:
+            continue
+        ok = True
+        for src, sha in j.get("sources", {}).items():
+            path = os.path.join(PKG, "csrc", src)
+            ok = ok and os.path.exists(path) and hashlib.sha1(open(path, "rb").read()).hexdigest() == sha
+        if not ok:
+            continue
+        tot = 0
+        for name, k in j.get("kernels", {}).items():
+            if kernel_substr in name:
+                tot += k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+        if tot:
+            best = {"bytes": int(tot), "file": "profiles/" + f}
+    return best
+
+
+def timed_replays(replay, n):
+    import torch
+    for _ in range(20):
+        replay()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n):
+        replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t1) / n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp32", choices=["bf16", "fp16", "fp32"],
+                    help="storage of the headline run; fp32 = the parity-grade mode (split bf16 MFMA operands)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the bf16 / fp16 storage legs")
     ap.add_argument("--no-conditioning", action="store_true", help="skip the embedding-extractor leg")
     ap.add_argument("--no-v3", action="store_true", help="skip the plain HiFi-GAN V3 leg (BASELINE configs[0])")
-    ap.add_argument("--no-48k", action="store_true", help="skip the 48 kHz fp16 leg (BASELINE configs[4] shapes)")
+    ap.add_argument("--no-48k", action="store_true", help="skip the 48 kHz leg (BASELINE configs[4] shapes)")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying a HIP graph")
     ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     import torch.distributed as dist
     # one process per GPU over RCCL ("nccl").  MV_DIST_BACKEND=gloo lets several ranks share one device for a rehearsal
     backend = os.environ.get("MV_DIST_BACKEND", "nccl")
@@ -180,24 +262,32 @@ def main():
     import hifigan_modified as H
     from hifigan_modified import _native
     _native.lib()  # no fallback: raise if the HIP library is absent
+    from hifigan_modified.graphs import GraphedVocoder
 
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    dtype = getattr(torch, DT[args.dtype])
     torch.manual_seed(0)
-    gen = H.ModifiedHiFiGANGenerator()
-    sd_cpu = {k: v.detach().clone() for k, v in gen.state_dict().items()}
-    gen = gen.to(dev).to(dtype).train(False)
+    gen0 = H.ModifiedHiFiGANGenerator()
+    sd_cpu = {k: v.detach().clone() for k, v in gen0.state_dict().items()}
     B, Tm = args.batch, args.frames
     torch.manual_seed(1 + rank)
-    mel = torch.randn(B, 80, Tm, device=dev).to(dtype)
-    spk = torch.randn(B, 192, device=dev).to(dtype)
-    emo = torch.randn(B, 384, device=dev).to(dtype)
+    mel32 = torch.randn(B, 80, Tm, device=dev)
+    spk32 = torch.randn(B, 192, device=dev)
+    emo32 = torch.randn(B, 384, device=dev)
+
+    def build(dt):
+        g = H.ModifiedHiFiGANGenerator()
+        g.load_state_dict(sd_cpu)
+        g = g.to(dev).to(dt).train(False)
+        return g, mel32.to(dt), spk32.to(dt), emo32.to(dt)
+
+    gen, mel, spk, emo = build(dtype)
 
     # waveforms of 2 clips of this very configuration, checked against the oracle in the CPU leg (cpu_baseline)
     checks = {}
+    host = lambda t: t.float().cpu()
     if rank == 0:
         with torch.no_grad():
-            checks["headline"] = (gen(mel[:2], spk[:2], emo[:2]).float().cpu(),
-                                  (mel[:2].float().cpu(), spk[:2].float().cpu(), emo[:2].float().cpu()))
+            checks["headline"] = (host(gen(mel[:2], spk[:2], emo[:2])), (host(mel[:2]), host(spk[:2]), host(emo[:2])))
 
     if args.eager:
         def step():
@@ -205,7 +295,6 @@ def main():
                 return gen(mel, spk, emo)
     else:
         # one HIP graph per step: the ~20 launches of a forward are host-bound when issued eagerly
-        from hifigan_modified.graphs import GraphedVocoder
         graphed = GraphedVocoder(gen, mel, spk, emo)
         step = graphed.replay
 
@@ -238,124 +327,96 @@ def main():
 
     # live roofline of the MRF ("ResBlock") stage: HIP events on the launch stream (torch's current stream) around
     # the fused channels-last block = 3 launches of mv::mrf_kernel<T,...,PASS=1|2|3> (GN5 stats, GN8 stats, output)
-    roof = None
-    if rank == 0:
-        from hifigan_modified import ops
-        from hifigan_modified.fused import generator_fused_for
-        fz = generator_fused_for(gen)
+    from hifigan_modified import ops
+    from hifigan_modified.fused import generator_fused_for
+
+    def mrf_roofline(g, m, s, e, tag):
+        fzz = generator_fused_for(g)
         with torch.no_grad():
-            st = gen(mel, spk, emo, return_stages=True)
-            x_cl = ops.nct_to_ntc(st["up%d" % (len(gen.upsample_layers) - 1)])
-            run = (lambda: fz.mrfs[0].forward_cl(x_cl)) if fz is not None else (lambda: gen.mrf_blocks[0](st["up3"]))
+            st_ = g(m, s, e, return_stages=True)
+            x_cl = ops.nct_to_ntc(st_["up%d" % (len(g.upsample_layers) - 1)])
+            run = (lambda: fzz.mrfs[0].forward_cl(x_cl)) if fzz is not None else (lambda: g.mrf_blocks[0](st_["up3"]))
             ms = graph_time_ms(run)
-        elt = torch.tensor([], dtype=dtype).element_size()
-        alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block, once (256 B / sample in bf16)
+        elt = x_cl.element_size()
+        alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block, once (64 ch in + 64 ch out per sample)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "mv::mrf_kernel (fused MRF block = 3 pass launches)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per block from the PMC passes committed in profiles/r01_pmc_traffic_bf16.csv (separate --pmc FETCH_SIZE /
-                # WRITE_SIZE runs of this command, FETCH_SIZE doubled per the gfx950 correction): 34.3 + 34.6 + 35.3 MB read,
-                # 34.0 MB written, at this exact workload
-                "traffic": 138_200_000 if (args.dtype == "bf16" and B == 32 and Tm == 32) else None,
-                "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
-                "note": "3 passes read x once each and write once: actual HBM bytes = 2x algorithmic; the block also issues 512 MFMAs "
-                        "per 64-step tile (stage 1 is recomputed in every pass, tap/row padding included) = 27 us of matrix-pipe time at "
-                        "B=32 x 8192, so about half of the block time is MFMA issue, not memory"}
+        tr = pmc_traffic("mrf_kernel", tag) if (B == 32 and Tm == 32) else None
+        r = {"bound": "hbm", "kernel": "mv::mrf_kernel<%s> (fused MRF block = 3 pass launches)" % tag, "achieved": round(achieved, 1),
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "traffic": tr["bytes"] if tr else None, "traffic_source": tr["file"] if tr else None,
+             "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
+             "note": "3 passes read x once each and write once (GroupNorm is global in T): actual HBM bytes = 2x algorithmic; "
+                     "with split operands (fp32 storage) the block issues 3 MFMAs per product and is matrix-pipe / LDS bound"}
+        return r, st_, fzz
 
-    # per-kernel HBM figures of the HBM-bound fused ODConvTranspose1d launches ((Cin/f + Cout) * 2 B per output sample)
-    od_roof = None
-    if rank == 0 and fz is not None:
-        od_roof = []
-        with torch.no_grad():
-            for li in (len(fz.ups) - 2, len(fz.ups) - 1):
-                u = fz.ups[li]
-                xin = ops.nct_to_ntc(st["up%d" % (li - 1)] if li > 0 else st["film"])
-                pooled = xin.float().sum(dim=1).contiguous()
-                from hifigan_modified import functional as _Fn
-                run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1)
-                y = run()
-                ms_u = graph_time_ms(run)
-                byts = (xin.numel() + y.numel()) * elt
-                od_roof.append({"kernel": "mv::odconv_cl_kernel (upsample_layers.%d: %d->%d ch, x%d)" % (li, u.mod.in_channels, u.mod.out_channels, u.mod.stride),
-                                "bound": "hbm", "achieved": round(byts / (ms_u * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(byts / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": byts,
-                                "ms_per_launch": round(ms_u, 4)})
-
-    # ---------------------------------------------------------------- parity-grade mode (fp32 storage, bf16x3 MFMA operands)
-    # The headline runs the BASELINE-named bf16 configuration, whose waveform parity is bounded by 16-bit activation
-    # storage.  The same generator with fp32 storage meets north_star's 1e-3 tolerance; its
-    # throughput and parity are reported beside the headline (rank 0, N=1 only; same workload, same HIP-graph replay).
-    parity_grade = None
-    if rank == 0 and world == 1 and dtype != torch.float32 and not args.eager:
-        from hifigan_modified.graphs import GraphedVocoder
-        g32 = H.ModifiedHiFiGANGenerator()
-        g32.load_state_dict(sd_cpu)
-        g32 = g32.to(dev).train(False)
-        m32, s32, e32 = mel.float(), spk.float(), emo.float()
-        with torch.no_grad():
-            checks["parity_grade"] = (g32(m32[:2], s32[:2], e32[:2]).cpu(), (m32[:2].cpu(), s32[:2].cpu(), e32[:2].cpu()))
-        gv32 = GraphedVocoder(g32, m32, s32, e32)
-        for _ in range(20):
-            gv32.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n32 = 200
-        for _ in range(n32):
-            gv32.replay()
-        torch.cuda.synchronize()
-        el32 = time.perf_counter() - t1
-        parity_grade = {"dtype": "fp32", "value": round(B * Tm * n32 / el32, 1), "unit": "mel-frames/s",
-                        "ms_per_step": round(el32 / n32 * 1e3, 4), "parity_rel_l2_vs_oracle": None}
-        del gv32, g32
-        # the same kernels with fp16 storage: the throughput of the bf16 headline, 10x closer to the oracle (3 more mantissa bits)
-        if dtype == torch.bfloat16:
-            g16 = H.ModifiedHiFiGANGenerator()
-            g16.load_state_dict(sd_cpu)
-            g16 = g16.to(dev).half().train(False)
-            m16, s16, e16 = mel.half(), spk.half(), emo.half()
+    roof = od_roof = None
+    if rank == 0:
+        roof, st, fz = mrf_roofline(gen, mel, spk, emo, args.dtype)
+        # per-kernel HBM figures of the HBM-bound fused ODConvTranspose1d launches ((Cin/f + Cout) * es B per output sample)
+        if fz is not None:
+            od_roof = []
+            from hifigan_modified import functional as _Fn
+            elt = mel.element_size()
             with torch.no_grad():
-                checks["fp16_storage"] = (g16(m16[:2], s16[:2], e16[:2]).float().cpu(),
-                                          (m16[:2].float().cpu(), s16[:2].float().cpu(), e16[:2].float().cpu()))
-            gv16 = GraphedVocoder(g16, m16, s16, e16)
-            for _ in range(20):
-                gv16.replay()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(n32):
-                gv16.replay()
-            torch.cuda.synchronize()
-            el16 = time.perf_counter() - t1
-            parity_grade["fp16_storage"] = {"value": round(B * Tm * n32 / el16, 1), "ms_per_step": round(el16 / n32 * 1e3, 4),
-                                            "parity_rel_l2_vs_oracle": None}
-            del gv16, g16
+                for li in (len(fz.ups) - 2, len(fz.ups) - 1):
+                    u = fz.ups[li]
+                    xin = ops.nct_to_ntc(st["up%d" % (li - 1)] if li > 0 else st["film"])
+                    pooled = xin.float().sum(dim=1).contiguous()
+                    run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1)
+                    y = run()
+                    ms_u = graph_time_ms(run)
+                    byts = (xin.numel() + y.numel()) * elt
+                    od_roof.append({"kernel": "mv::odconv_cl_*_kernel<%s> (upsample_layers.%d: %d->%d ch, x%d)" % (args.dtype, li, u.mod.in_channels, u.mod.out_channels, u.mod.stride),
+                                    "bound": "hbm", "achieved": round(byts / (ms_u * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(byts / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": byts,
+                                    "ms_per_launch": round(ms_u, 4)})
+        del st
 
-    # ---------------------------------------------------------------- BASELINE configs[4]: 48 kHz variant, fp16, single-GPU share
+    # ---------------------------------------------------------------- the 16-bit storage modes beside the headline (rank 0, N=1)
+    modes = None
+    if rank == 0 and world == 1 and not args.eager and not args.no_modes:
+        modes = {}
+        for tag in ("bf16", "fp16", "fp32"):
+            if tag == args.dtype:
+                continue
+            dt = getattr(torch, DT[tag])
+            g2, m2, s2, e2 = build(dt)
+            with torch.no_grad():
+                checks["mode_" + tag] = (host(g2(m2[:2], s2[:2], e2[:2])), (host(m2[:2]), host(s2[:2]), host(e2[:2])))
+            gv = GraphedVocoder(g2, m2, s2, e2)
+            el = timed_replays(gv.replay, 200)
+            modes[tag] = {"value": round(B * Tm / el, 1), "unit": "mel-frames/s", "ms_per_step": round(el * 1e3, 4),
+                          "parity_rel_l2_vs_oracle": None, "parity_ok": None}
+            if tag == "bf16":        # the BASELINE-named storage type: its MRF kernel against the same roofline
+                modes[tag]["roofline"] = mrf_roofline(g2, m2, s2, e2, tag)[0]
+            del gv, g2
+
+    # ---------------------------------------------------------------- BASELINE configs[4]: 48 kHz variant, single-GPU share
     # 128-mel, upsample [8,8,4,2] (hop 512), 16 mel frames -> 8192 samples, B=32 per GPU: same kernels, other shapes (ups2 = k8 s4).
-    cfg48 = None
+    # Timed in the parity-grade mode and in fp16 storage (the type configs[4] names).
+    cfg48 = checks48 = None
     if rank == 0 and world == 1 and not args.eager and not args.no_48k:
-        from hifigan_modified.graphs import GraphedVocoder
         torch.manual_seed(0)
-        g48 = H.ModifiedHiFiGANGenerator(mel_channels=128, upsample_factors=[8, 8, 4, 2])
-        sd48 = {k: v.detach().clone() for k, v in g48.state_dict().items()}
-        g48 = g48.to(dev).half().train(False)
+        g48c = H.ModifiedHiFiGANGenerator(mel_channels=128, upsample_factors=[8, 8, 4, 2])
+        sd48 = {k: v.detach().clone() for k, v in g48c.state_dict().items()}
         torch.manual_seed(1)
-        m48 = torch.randn(B, 128, 16, device=dev).half()
-        with torch.no_grad():
-            checks48 = (g48(m48[:2], spk[:2].half(), emo[:2].half()).float().cpu(), (m48[:2].float().cpu(), spk[:2].float().cpu(), emo[:2].float().cpu()), sd48)
-        gv48 = GraphedVocoder(g48, m48, spk.half(), emo.half())
-        for _ in range(20):
-            gv48.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        n48 = 200
-        for _ in range(n48):
-            gv48.replay()
-        torch.cuda.synchronize()
-        el48 = time.perf_counter() - t1
-        cfg48 = {"workload": "configs[4] per-GPU share: 128-mel 48 kHz generator, upsample [8,8,4,2], B=%d x 16 mel frames -> 8192 samples, fp16" % B,
-                 "value": round(B * 16 * n48 / el48, 1), "unit": "mel-frames/s", "samples_per_s": round(B * 8192 * n48 / el48, 1),
-                 "ms_per_step": round(el48 / n48 * 1e3, 4), "dtype": "fp16", "launch": "hipgraph", "parity_rel_l2_vs_oracle": None}
-        del gv48, g48
+        m48 = torch.randn(B, 128, 16, device=dev)
+        cfg48 = {"workload": "configs[4] per-GPU share: 128-mel 48 kHz generator, upsample [8,8,4,2], B=%d x 16 mel frames -> 8192 samples" % B}
+        checks48 = {}
+        for tag in ("fp32", "fp16"):
+            dt = getattr(torch, DT[tag])
+            g48 = H.ModifiedHiFiGANGenerator(mel_channels=128, upsample_factors=[8, 8, 4, 2])
+            g48.load_state_dict(sd48)
+            g48 = g48.to(dev).to(dt).train(False)
+            mm, ss, ee = m48.to(dt), spk32.to(dt), emo32.to(dt)
+            with torch.no_grad():
+                checks48[tag] = host(g48(mm[:2], ss[:2], ee[:2]))
+            gv48 = GraphedVocoder(g48, mm, ss, ee)
+            el48 = timed_replays(gv48.replay, 200)
+            cfg48[tag] = {"value": round(B * 16 / el48, 1), "unit": "mel-frames/s", "samples_per_s": round(B * 8192 / el48, 1),
+                          "ms_per_step": round(el48 * 1e3, 4), "launch": "hipgraph", "parity_rel_l2_vs_oracle": None, "parity_ok": None}
+            del gv48, g48
+        checks48 = (checks48, (host(m48[:2]), host(spk32[:2]), host(emo32[:2])), sd48)
 
     # ---------------------------------------------------------------- BASELINE configs[0]: plain HiFi-GAN V3 (no ODConv), batch 1
     # the reference's own CPU-runnable case (fairseq's generator: parity unpinned); GPU figure + the CPU restatement timed
@@ -370,59 +431,59 @@ def main():
         mel_v3 = torch.randn(1, 80, 344, device=dev)
         with torch.no_grad():
             w_v3 = v3(mel_v3)
+            launch = "eager"
+            run_v3 = lambda: v3(mel_v3)
+            if not args.eager and hasattr(v3, "graphed"):
+                run_v3 = v3.graphed(mel_v3)
+                launch = "hipgraph"
             for _ in range(3):
-                v3(mel_v3)
+                run_v3()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n_v3 = 20
+            n_v3 = 50
             for _ in range(n_v3):
-                v3(mel_v3)
+                run_v3()
             torch.cuda.synchronize()
             el_v3 = time.perf_counter() - t1
         check_v3 = (w_v3.cpu(), mel_v3.cpu(), sd_v3)
-        cfg_v3 = {"workload": "configs[0]: plain HiFi-GAN V3 generator, B=1 x 344 mel frames (4 s at 22.05 kHz), fp32, generic HIP kernels, eager",
+        cfg_v3 = {"workload": "configs[0]: plain HiFi-GAN V3 generator, B=1 x 344 mel frames (4 s at 22.05 kHz), fp32",
                   "value": round(344 * n_v3 / el_v3, 1), "unit": "mel-frames/s", "ms_per_step": round(el_v3 / n_v3 * 1e3, 3), "dtype": "fp32",
-                  "parity_rel_l2_vs_cpu_restatement": None, "cpu": None, "note": "parity unpinned: fairseq generator absent from the reference tree"}
+                  "launch": launch, "parity_rel_l2_vs_cpu_restatement": None, "cpu": None,
+                  "note": "parity unpinned: fairseq generator absent from the reference tree"}
         del v3
 
     # ---------------------------------------------------------------- conditioning producers
     # ECAPA-TDNN + Emotion2Vec on the same mel batch (what ModifiedHiFiGANVocoder.forward(extract_embeddings=True) runs in front
     # of the generator): throughput of the captured forward, the dominant kernel's roofline, parity against the CPU oracle.
     conditioning, embed_check = None, None
-    if rank == 0 and world == 1 and dtype != torch.float32 and not args.eager and not args.no_conditioning:
+    if rank == 0 and world == 1 and not args.eager and not args.no_conditioning:
         from hifigan_modified.graphs import GraphedExtractor
-        from hifigan_modified import ops as _ops, _native as _N
+        from hifigan_modified import _native as _N
+        cdt = torch.bfloat16
+        melc = mel32.to(cdt)
         torch.manual_seed(0)
         ex = H.EmbeddingExtractor().to(dev).train(False)
         with torch.no_grad():
             for bn in [m for m in ex.modules() if isinstance(m, torch.nn.BatchNorm1d)]:      # non-trivial running statistics
                 bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5); bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
-            s2, e2 = ex(mel[:2])
-        embed_check = ({k: v.detach().float().cpu() for k, v in ex.state_dict().items()}, mel[:2].float().cpu(), s2.float().cpu(), e2.float().cpu())
-        ge = GraphedExtractor(ex, mel)
-        for _ in range(20):
-            ge.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        nE = 200
-        for _ in range(nE):
-            ge.replay()
-        torch.cuda.synchronize()
-        elE = time.perf_counter() - t1
+            s2, e2 = ex(melc[:2])
+        embed_check = ({k: v.detach().float().cpu() for k, v in ex.state_dict().items()}, host(melc[:2]), host(s2), host(e2))
+        ge = GraphedExtractor(ex, melc)
+        elE = timed_replays(ge.replay, 200)
         # dominant kernel: the split-K GEMM of the 512 -> 512 layers (27 of ~80 launches per forward)
         Mr, Kd, Nd = B * Tm, 512, 512
-        xg = torch.randn(Mr, Kd, device=dev).to(dtype)
-        wg = _ops.dconv_pack((torch.randn(Nd, Kd, 1, 1, device=dev) / Kd ** 0.5), dtype, 0)
-        bg = torch.zeros(Nd, device=dev, dtype=dtype)
-        yg = torch.empty(Mr, Nd, device=dev, dtype=dtype)
-        run = lambda: _N.call("mv_gemm_cl_skinny", _ops._p(xg), _ops._p(wg), _ops._p(bg), _ops._p(yg), Mr, Kd, Nd, _N.ACT_LRELU, 0.0,
-                              _ops._dt(xg), _ops._stream())
+        xg = torch.randn(Mr, Kd, device=dev).to(cdt)
+        wg = ops.dconv_pack((torch.randn(Nd, Kd, 1, 1, device=dev) / Kd ** 0.5), cdt, 0)
+        bg = torch.zeros(Nd, device=dev, dtype=cdt)
+        yg = torch.empty(Mr, Nd, device=dev, dtype=cdt)
+        run = lambda: _N.call("mv_gemm_cl_skinny", ops._p(xg), ops._p(wg), ops._p(bg), ops._p(yg), Mr, Kd, Nd, _N.ACT_LRELU, 0.0,
+                              ops._dt(xg), ops._stream())
         msg = graph_time_ms(run)
         gb = (Mr * Kd + Nd * Kd + Mr * Nd) * 2
         conditioning = {"metric": "mel-frames/s embedded (ECAPA-TDNN speaker + Emotion2Vec emotion encoders)",
-                        "value": round(B * Tm * nE / elE, 1), "unit": "mel-frames/s", "ms_per_step": round(elE / nE * 1e3, 4), "dtype": args.dtype,
+                        "value": round(B * Tm / elE, 1), "unit": "mel-frames/s", "ms_per_step": round(elE * 1e3, 4), "dtype": "bf16",
                         "launch": "hipgraph", "parity_rel_l2_vs_oracle": None,
-                        "roofline": {"bound": "hbm", "kernel": "mv::gemm_skinny_kernel<%s,2> (%dx%dx%d, split-K over 8 waves)" % (args.dtype, Mr, Nd, Kd),
+                        "roofline": {"bound": "hbm", "kernel": "mv::gemm_skinny_kernel<bf16,2> (%dx%dx%d, split-K over 8 waves)" % (Mr, Nd, Kd),
                                      "achieved": round(gb / (msg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(gb / (msg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": gb,
                                      "ms_per_launch": round(msg, 4),
@@ -431,16 +492,17 @@ def main():
 
     # ---------------------------------------------------------------- training metric (BASELINE configs[2]/[3])
     # full two-optimizer step (complete_vocoder.py:199-233): G forward -> D step -> G step, + mel/STFT loss, + AdamW;
-    # data parallel: 32 clips per GPU, one all-reduce of the flat gradient buffer per optimizer step (RCCL)
+    # data parallel: 32 clips per GPU; each optimizer's gradient buckets are all-reduced (RCCL) from grad-ready hooks while
+    # its backward is still running (parallel.OverlappedGradSync)
     train = None
     if args.train_steps > 0:
-        from hifigan_modified.parallel import GradSynchronizer, broadcast_parameters
-        tdtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.train_dtype]
+        from hifigan_modified.parallel import broadcast_parameters
+        tdtype = getattr(torch, DT[args.train_dtype])
         torch.manual_seed(0)
         voc = H.ModifiedHiFiGANVocoder().to(dev)
         if world > 1:
             broadcast_parameters(voc)
-        trainer = H.VocoderTrainer(voc, device=dev, grad_sync=GradSynchronizer() if world > 1 else None)
+        trainer = H.VocoderTrainer(voc, device=dev)       # grad_sync defaults to "overlap" when world > 1
         torch.manual_seed(100 + rank)
         tmel = torch.randn(B, 80, Tm, device=dev).to(tdtype)
         treal = torch.randn(B, 1, Tm * 256, device=dev).clamp(-1, 1).to(tdtype)
@@ -448,6 +510,9 @@ def main():
         torch.manual_seed(2 + rank)      # dropout stream of this rank
         for _ in range(args.train_warmup):
             losses = trainer.train_step(tmel, treal, tspk, temo, return_tensors=True)
+        ovs = [o for o in (trainer.overlap_sync(trainer.generator_optimizer), trainer.overlap_sync(trainer.discriminator_optimizer)) if o is not None]
+        for o in ovs:
+            o.timing, o.exposed_ms, o.reduced_bytes, o._ev = True, 0.0, 0, []
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.train_steps):
@@ -463,11 +528,17 @@ def main():
                  "value": round(B * Tm * 256 * world * args.train_steps / tel, 1), "unit": "samples/s",
                  "ms_per_step": round(tel / args.train_steps * 1e3, 2), "steps": args.train_steps, "dtype": args.train_dtype,
                  "global_batch": B * world, "losses_finite": all(x == x and abs(x) != float("inf") for x in lf.values()),
-                 "parallelism": "dp%d, flat-bucket all-reduce over RCCL" % world if world > 1 else "single GPU"}
+                 "parallelism": ("dp%d, gradient buckets all-reduced over RCCL under the backward" % world) if world > 1 else "single GPU"}
+        if ovs:
+            exposed = sum(o.collect_timing() for o in ovs) / args.train_steps
+            nbytes = sum(o.reduced_bytes for o in ovs) / args.train_steps
+            train["allreduce"] = {"bytes_per_step": int(nbytes), "buckets": sum(len(o.buckets) for o in ovs),
+                                  "exposed_wait_ms_per_step": round(exposed, 3),
+                                  "note": "exposed = time the compute stream waited for the collectives after the backward (what the overlap did not hide)"}
         if rank == 0 and tdtype != torch.float32:
             # MFMA roofline of the dominant discriminator conv (128 -> 256, 3x3, period-2 fold of the real+fake batch)
             import ctypes
-            from hifigan_modified import ops as _ops, _native as _N, disc_fused as _df
+            from hifigan_modified import _native as _N, disc_fused as _df
             conv = voc.discriminators.mpd.discriminators[0].conv_layers[6]
             Bd, Hd, Wd = 2 * B, 2, Tm * 256 // 2
             xin = torch.randn(Bd, Hd, Wd, 128, device=dev).to(tdtype)
@@ -477,7 +548,7 @@ def main():
             P = lambda t: ctypes.c_void_p(t.data_ptr())
             def run():
                 _N.call("mv_dconv_cl_fwd", P(xin), P(pk), P(bias), None, P(yout), Bd, Hd, Wd, 128, 256, 3, 3, 1, _N.ACT_LRELU, 0.1,
-                        _ops._dt(xin), _ops._stream())
+                        ops._dt(xin), ops._stream())
             for _ in range(3):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -489,36 +560,43 @@ def main():
             ms = e0.elapsed_time(e1) / 10
             flops = 2.0 * Bd * Hd * Wd * 256 * 128 * 9
             ach = flops / (ms * 1e-3) / 1e12
-            train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_wide_kernel<bf16,2,4,8,64> (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM, 8 waves: 256 rows x 256 positions)",
+            ttr = pmc_traffic("dconv_cl_wide_kernel", "train_" + args.train_dtype)
+            train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_wide_kernel<%s,2,4,8,64> (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM, 8 waves: 256 rows x 256 positions)" % args.train_dtype,
                                  "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                                 "traffic": None, "flops_per_launch": flops, "ms_per_launch": round(ms, 4)}
+                                 "traffic": ttr["bytes"] if ttr else None, "flops_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
     if rank == 0:
         frames = B * Tm * world * args.steps
+        precision = {"fp32": "fp32 storage; every MFMA operand split into hi + lo bf16 (3 products per MAC), fp32 accumulate",
+                     "bf16": "bf16 storage and MFMA operands, fp32 accumulate", "fp16": "fp16 storage and MFMA operands, fp32 accumulate"}[args.dtype]
         out = {
             "metric": "mel-frames/s vocoded (V1 80-mel 22.05kHz generator, ODConv + GRC-LoRA)",
             "value": round(frames / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "precision": precision, "data": "synthetic",
             "config": {"workload": "configs[1]: V1 generator + ODConv1d + GRC-LoRA, B=%d x %d mel frames -> %d samples, inference"
                                    % (B, Tm, Tm * 256), "batch_per_gpu": B, "mel_frames": Tm, "n_mels": 80,
                        "parallelism": "replicas (batch-sharded, no collective)"},
             "samples_per_s": round(frames * 256 / elapsed, 1),
-            "parity_rel_l2_vs_oracle": None, "launch": "eager" if args.eager else "hipgraph",
+            "parity_rel_l2_vs_oracle": None, "parity_tol": PARITY_TOL, "parity_ok": None,
+            "launch": "eager" if args.eager else "hipgraph",
             "roofline": roof,
             "roofline_odconv": od_roof,
-            "parity_grade": parity_grade,
+            "modes": modes,
             "train": train,
             "conditioning": conditioning,
-            "config_48k_fp16": cfg48,
+            "config_48k": cfg48,
             "config_v3_plain": cfg_v3,
         }
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline(sd_cpu, max(1, (os.cpu_count() or 2) // 2), checks=checks, embed_check=embed_check,
-                              check48=checks48 if cfg48 is not None else None, check_v3=check_v3)
+                              check48=checks48, check_v3=check_v3)
             par = cb.pop("parity", {})
+            ok = lambda v: None if v is None else bool(v <= PARITY_TOL)
             if cfg48 is not None:
-                cfg48["parity_rel_l2_vs_oracle"] = par.get("config_48k_fp16")
+                for tag in ("fp32", "fp16"):
+                    cfg48[tag]["parity_rel_l2_vs_oracle"] = par.get("config_48k_" + tag)
+                    cfg48[tag]["parity_ok"] = ok(par.get("config_48k_" + tag))
             if cfg_v3 is not None:
                 cfg_v3["parity_rel_l2_vs_cpu_restatement"] = par.get("config_v3_plain")
                 cfg_v3["cpu"] = cb.pop("config_v3_plain", None)
@@ -526,10 +604,10 @@ def main():
                 conditioning["parity_rel_l2_vs_oracle"] = par.get("conditioning")
                 conditioning["cpu_baseline"] = cb.pop("conditioning", None)
             out["parity_rel_l2_vs_oracle"] = par.get("headline")
-            if parity_grade is not None:
-                parity_grade["parity_rel_l2_vs_oracle"] = par.get("parity_grade")
-                if "fp16_storage" in parity_grade:
-                    parity_grade["fp16_storage"]["parity_rel_l2_vs_oracle"] = par.get("fp16_storage")
+            out["parity_ok"] = ok(par.get("headline"))
+            for tag in (modes or {}):
+                modes[tag]["parity_rel_l2_vs_oracle"] = par.get("mode_" + tag)
+                modes[tag]["parity_ok"] = ok(par.get("mode_" + tag))
             out["cpu_baseline"] = cb
         print(json.dumps(out))
     if world > 1:

@@ -119,3 +119,20 @@ def test_film_condition_glue():
     c = f2.condition(spk, emo)
     assert c.shape == (2, 600) and torch.equal(c[:, :192], spk) and c[:, 576:].abs().sum() == 0
     assert f.condition(None, None) is None
+
+
+def test_mel_loss_rejects_wrong_shapes_before_any_launch():
+    """ops.mel_loss checks what the C entry point cannot (it receives no sizes for target / filterbank): a target with one
+    frame too many (a center=True front-end), another n_mels, an fb built for another n_fft or a ragged T raise ValueError
+    like the reference's F.l1_loss / F.mse_loss would - instead of reading out of bounds on the device."""
+    from hifigan_modified import ops
+    wave, fb = torch.zeros(2, 1, 2048), torch.zeros(80, 513)
+    for bad_target in (torch.zeros(2, 80, 9), torch.zeros(2, 64, 8), torch.zeros(1, 80, 8)):
+        with pytest.raises(ValueError, match="target"):
+            ops.mel_loss(wave, fb, bad_target, n_fft=1024, hop=256)
+    with pytest.raises(ValueError, match="filterbank"):
+        ops.mel_loss(wave, torch.zeros(80, 257), torch.zeros(2, 80, 8), n_fft=1024, hop=256)
+    with pytest.raises(ValueError, match="multiple of hop"):
+        ops.mel_loss(torch.zeros(2, 1, 2000), fb, torch.zeros(2, 80, 7), n_fft=1024, hop=256)
+    with pytest.raises(ValueError, match=r"\[B, 1, T\]"):
+        ops.mel_loss(torch.zeros(2, 2, 2048), fb, torch.zeros(2, 80, 8), n_fft=1024, hop=256)

@@ -1,0 +1,105 @@
+"""Turn raw rocprofv3 output into the summaries committed under profiles/ (so the evidence is reproducible).
+
+  kernel stats:   python tools/profile_summary.py stats  <rocprof dir> profiles/rNN_<what>_kernel_stats.csv
+      <rocprof dir> holds *_kernel_trace.csv (rocprofv3 --kernel-trace ... --output-format csv); the summary is one row per
+      kernel: calls, total / average / min / max duration in ns, share of the GPU time - what `--stats` prints, recomputed
+      from the trace so that it does not depend on the profiler version's own stats file.
+
+  HBM traffic:    python tools/profile_summary.py traffic <FETCH_SIZE dir> <WRITE_SIZE dir> profiles/rNN_<dtype>_pmc_traffic.json \
+                         --dtype fp32 --workload "bench.py --dtype fp32 --train-steps 0 ..."
+      The two directories come from two SEPARATE passes (`rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE
+      --kernel-trace`; gfx950 cannot count both at once, and counter passes must not be mixed with the trace domains gpurun
+      refuses).  Units and the gfx950 correction follow MI355X_MICROARCH.md, section HBM: both counters are in KiB per
+      dispatch; FETCH_SIZE reports half of the bytes of a wide coalesced read, so it is doubled; WRITE_SIZE is exact.
+      The JSON also records the sha1 of every csrc/*.hip|*.h at profiling time: bench.py only quotes `roofline.traffic`
+      from a summary whose kernel sources are the ones it is running.
+"""
+import argparse
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "a-modified-hifi-gan-vocoder-using-odconv-and-grc-for-expressive-voice-cloning-_amd", "csrc")
+
+
+def _rows(d, pattern):
+    files = sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True))
+    if not files:
+        sys.exit(f"no {pattern} under {d}")
+    for f in files:
+        with open(f, newline="") as fh:
+            yield from csv.DictReader(fh)
+
+
+def short(name, n=160):
+    return name if len(name) <= n else name[:n]
+
+
+def stats(args):
+    agg = defaultdict(list)
+    for r in _rows(args.dir, "*kernel_trace.csv"):
+        agg[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in agg.values())
+    with open(args.out, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 2), min(v), max(v)])
+    print(f"{args.out}: {len(agg)} kernels, {total / 1e6:.2f} ms of GPU time")
+
+
+def traffic(args):
+    def per_kernel(d, counter):
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in _rows(d, "*counter_collection.csv"):
+            if r["Counter_Name"] != counter:
+                continue
+            a = acc[r["Kernel_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+        return acc
+    fe, wr = per_kernel(args.fetch_dir, "FETCH_SIZE"), per_kernel(args.write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        nf, sf = fe.get(k, [0, 0.0])
+        nw, sw = wr.get(k, [0, 0.0])
+        kernels[short(k)] = {"launches": max(nf, nw),
+                             "fetch_bytes_per_launch": round(2.0 * 1024.0 * sf / nf) if nf else 0,     # KiB -> B, x2 (gfx950)
+                             "write_bytes_per_launch": round(1024.0 * sw / nw) if nw else 0}
+    sources = {}
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            sources[f] = hashlib.sha1(open(os.path.join(CSRC, f), "rb").read()).hexdigest()
+    out = {"dtype": args.dtype, "workload": args.workload,
+           "method": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace; per-dispatch KiB averaged per "
+                     "kernel; FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read), WRITE_SIZE as read",
+           "sources": sources, "kernels": kernels}
+    with open(args.out, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(f"{args.out}: {len(kernels)} kernels")
+    for k, v in kernels.items():
+        if "mrf_kernel" in k or "odconv" in k or "conv_out" in k:
+            print(f"  {k[:100]:100s} R {v['fetch_bytes_per_launch'] / 1e6:8.2f} MB  W {v['write_bytes_per_launch'] / 1e6:8.2f} MB  x{v['launches']}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    a = sub.add_parser("stats")
+    a.add_argument("dir")
+    a.add_argument("out")
+    a.set_defaults(fn=stats)
+    b = sub.add_parser("traffic")
+    b.add_argument("fetch_dir")
+    b.add_argument("write_dir")
+    b.add_argument("out")
+    b.add_argument("--dtype", required=True)
+    b.add_argument("--workload", default="")
+    b.set_defaults(fn=traffic)
+    args = ap.parse_args()
+    args.fn(args)
