@@ -261,4 +261,7 @@ def disc_stack(x0, blk, slope=0.1):
     params = []
     for c in convs:
         params += [c.weight, c.bias]
+    from . import functional as Fn
+    if Fn.DISPATCH == "torch_ops":
+        return Fn._t().OPS.disc_conv_stack(x0, float(slope), *params)
     return _DiscStack.apply(x0, slope, *params)

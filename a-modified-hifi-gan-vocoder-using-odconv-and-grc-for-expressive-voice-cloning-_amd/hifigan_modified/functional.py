@@ -17,6 +17,21 @@ from . import ops
 _cache = ops._ParamCache()
 _ACT = {None: N.ACT_NONE, "none": N.ACT_NONE, "lrelu": N.ACT_LRELU, "tanh": N.ACT_TANH, "silu": N.ACT_SILU}
 
+# The public functions below dispatch through the registered PyTorch operators (torch.ops.mi355x_vocoder.*, torch_ops.py), whose
+# forward / backward are the static methods of the Function classes in this file.  DISPATCH = "direct" calls Function.apply
+# instead (same kernels, no dispatcher round trip) - a debugging switch, the default is the operator path.
+import os as _os
+DISPATCH = _os.environ.get("MV_DISPATCH", "torch_ops")
+_T = None
+
+
+def _t():
+    global _T
+    if _T is None:
+        from . import torch_ops
+        _T = torch_ops
+    return _T
+
 
 def _w(p, like):
     return _cache.get(p, like.dtype)
@@ -122,11 +137,18 @@ def odconv_attention(x, att_w, att_b):
 
 
 def odconv1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, dilation=1, act=None, slope=0.1, fused=None):
+    if DISPATCH == "torch_ops":
+        t = _t()
+        return t.OPS.odconv1d(x, kernels, bias, att_w, att_b, stride, padding, 0, dilation, _ACT[act], slope, t.object_handle(fused))
     return _ODConv.apply(x, kernels, bias, att_w, att_b, (False, stride, padding, 0, dilation, _ACT[act], slope), fused)
 
 
 def odconv_transpose1d(x, kernels, bias, att_w, att_b, stride=1, padding=0, output_padding=0, dilation=1,
                        act=None, slope=0.1, fused=None):
+    if DISPATCH == "torch_ops":
+        t = _t()
+        return t.OPS.odconv_transpose1d(x, kernels, bias, att_w, att_b, stride, padding, output_padding, dilation, _ACT[act], slope,
+                                        t.object_handle(fused))
     return _ODConv.apply(x, kernels, bias, att_w, att_b, (True, stride, padding, output_padding, dilation, _ACT[act], slope),
                          fused)
 
@@ -212,6 +234,8 @@ class _Conv1d(Function):
 
 
 def conv1d(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, act=None, slope=0.1):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.conv1d(x, weight, bias, stride, padding, dilation, groups, _ACT[act], slope)
     return _Conv1d.apply(x, weight, bias, (stride, padding, dilation, groups, _ACT[act], slope))
 
 
@@ -245,6 +269,8 @@ class _Conv2d(Function):
 
 
 def conv2d(x, weight, bias, padding=(1, 1), act=None, slope=0.1):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.conv2d(x, weight, bias, padding[0], padding[1], _ACT[act], slope)
     return _Conv2d.apply(x, weight, bias, (tuple(padding), _ACT[act], slope))
 
 
@@ -275,6 +301,8 @@ class _GroupNorm(Function):
 
 
 def group_norm(x, gw, gb, G, eps=1e-5, act=None, slope=0.1, res=None, mask=None, mask_scale=1.0):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.group_norm(x, gw, gb, res, mask, G, eps, _ACT[act], slope, mask_scale)
     return _GroupNorm.apply(x, gw, gb, res, mask, (G, eps, _ACT[act], slope, mask_scale))
 
 
@@ -300,6 +328,8 @@ class _Film(Function):
 
 
 def film(x, cond, proj_w, proj_b, feature_dim):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.film(x, cond, proj_w, proj_b, feature_dim)
     return _Film.apply(x, cond, proj_w, proj_b, feature_dim)
 
 
@@ -576,6 +606,9 @@ def mrf_block(x, blk, force_generic=False, mask=None):
     fz = None if (force_generic or needs_grad or training_dropout) else mrf_fused_for(blk)
     if fz is not None:
         with torch.no_grad():
+            if DISPATCH == "torch_ops":
+                t = _t()
+                return t.OPS.grc_mrf_block(x, t.object_handle(fz))
             return ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x)))
     x = x if x.is_contiguous() else x.contiguous()
     branches = _mrf_merged_branches(x, blk) if _mrf_merged_ok(x, blk) else [_grc_generic(x, g) for g in blk.conv_layers]
@@ -678,7 +711,7 @@ def disc2d(x, blk):
     if T % blk.period == 0:
         h = x.contiguous().view(B, C, blk.period, T // blk.period)   # exact multiple: the fold is a pure view
     else:
-        h = _MpdFold.apply(x, blk.period)
+        h = _t().OPS.mpd_fold(x, blk.period) if DISPATCH == "torch_ops" else _MpdFold.apply(x, blk.period)
     from . import disc_fused
     if disc_fused.supported(x, blk):      # 16-bit storage: channels-last MFMA stack (csrc/disc_fused.hip)
         return disc_fused.disc_stack(h, blk)
@@ -689,7 +722,9 @@ def disc2d(x, blk):
 
 def disc1d(x, blk):
     """discriminators.py:109-117."""
-    h = _AvgPool.apply(x, blk.scale) if blk.scale > 1 else x
+    h = x
+    if blk.scale > 1:
+        h = _t().OPS.avg_pool1d(x, blk.scale) if DISPATCH == "torch_ops" else _AvgPool.apply(x, blk.scale)
     from . import disc_fused
     if disc_fused.supported(x, blk):
         return disc_fused.disc_stack(h, blk)
@@ -719,28 +754,34 @@ class _Loss(Function):
         return gx, gyt, None, None, None
 
 
+def _loss(x, y, kind, c, weight):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.gan_loss(x, y, kind, float(c), float(weight))
+    return _Loss.apply(x, y, kind, float(c), float(weight))
+
+
 def mse_const(x, c, weight=1.0):
     """mean((x - c)^2): F.mse_loss(x, ones/zeros) of complete_vocoder.py:104,157-158."""
-    return _Loss.apply(x, None, 0, float(c), float(weight))
+    return _loss(x, None, 0, c, weight)
 
 
 def l1(x, y, weight=1.0):
     """mean|x - y|: F.l1_loss of complete_vocoder.py:118,127."""
-    return _Loss.apply(x, y, 1, 0.0, float(weight))
+    return _loss(x, y, 1, 0.0, weight)
 
 
 def mse(x, y, weight=1.0):
-    return _Loss.apply(x, y, 4, 0.0, float(weight))
+    return _loss(x, y, 4, 0.0, weight)
 
 
 def hinge_g(x, weight=1.0):
     """mean(relu(1 - x)): conditioned_hifigan.py:263."""
-    return _Loss.apply(x, None, 2, 0.0, float(weight))
+    return _loss(x, None, 2, 0.0, weight)
 
 
 def hinge_d_fake(x, weight=1.0):
     """mean(relu(1 + x)): conditioned_hifigan.py:265."""
-    return _Loss.apply(x, None, 3, 0.0, float(weight))
+    return _loss(x, None, 3, 0.0, weight)
 
 
 class _MelL1(Function):
@@ -760,16 +801,24 @@ class _MelL1(Function):
         return (gw if ctx.dtype == torch.float32 else ops.cast(gw, ctx.dtype)), None, None, None, None, None, None, None
 
 
+def _mel(wave, target, fb, n_fft, hop, clampv, weight, kind):
+    if DISPATCH == "torch_ops":
+        return _t().OPS.mel_loss(wave, target, fb, n_fft, hop, float(clampv), float(weight), kind)
+    return _MelL1.apply(wave, target, fb, n_fft, hop, clampv, float(weight), kind)
+
+
 def mel_l1(wave, target, fb, n_fft=1024, hop=256, clampv=1e-5, weight=1.0):
-    return _MelL1.apply(wave, target, fb, n_fft, hop, clampv, float(weight), 0)
+    return _mel(wave, target, fb, n_fft, hop, clampv, weight, 0)
 
 
 def mel_mse(wave, target, fb, n_fft=1024, hop=256, clampv=1e-5, weight=1.0):
     """weight * mean (logmel(wave) - target)^2: the MSE mel term of conditioned_hifigan.py:238."""
-    return _MelL1.apply(wave, target, fb, n_fft, hop, clampv, float(weight), 1)
+    return _mel(wave, target, fb, n_fft, hop, clampv, weight, 1)
 
 
 def mel_spectrogram(wave, fb, n_fft=1024, hop=256, clampv=1e-5):
     """log-mel [B, n_mels, T/hop] (fp32) of a waveform [B,1,T]."""
     with torch.no_grad():
+        if DISPATCH == "torch_ops":
+            return _t().OPS.mel_spectrogram(wave, fb, n_fft, hop, float(clampv))
         return ops.mel_loss(wave, fb, None, n_fft, hop, clampv, 1.0, backward=False, want_mel=True)[1]

@@ -108,7 +108,10 @@ class ModifiedHiFiGANGenerator(nn.Module):
             fz = generator_fused_for(self)
             if fz is not None:
                 # inference fast path: channels-last MFMA pipeline (csrc/odconv_fused.hip, mrf_fused.hip, conv_out.hip)
-                return fz.forward(mel, speaker_emb, emotion_emb, cache=Fn._cache, return_stages=return_stages)
+                if return_stages or Fn.DISPATCH != "torch_ops":
+                    return fz.forward(mel, speaker_emb, emotion_emb, cache=Fn._cache, return_stages=return_stages)
+                t = Fn._t()      # one operator for the whole captured pipeline: torch.ops.mi355x_vocoder.generator_forward
+                return t.OPS.generator_forward(mel, speaker_emb, emotion_emb, t.object_handle(fz))
         st = {}
         x = self.input_proj(mel)
         st["input_proj"] = x

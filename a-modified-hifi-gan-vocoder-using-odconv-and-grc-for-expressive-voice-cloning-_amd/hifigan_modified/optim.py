@@ -123,12 +123,11 @@ class FlatAdamW:
                     i = j + 1
                 else:
                     i += 1
-        for off, cnt in runs:
-            b = 4 * off
-            N.call("mv_adamw_flat", c_void_p(self.flat_p.data_ptr() + b), c_void_p(self.flat_g.data_ptr() + b),
-                   c_void_p(self.exp_avg.data_ptr() + b), c_void_p(self.exp_avg_sq.data_ptr() + b), cnt, float(self.lr),
-                   float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                   int(self.step_count), float(grad_scale), ops._stream())
+        from .torch_ops import OPS
+        for off, cnt in runs:            # torch.ops.mi355x_vocoder.fused_adamw_ (in place on the arena slices; mv_adamw_flat)
+            OPS.fused_adamw_(self.flat_p[off:off + cnt], self.flat_g[off:off + cnt], self.exp_avg[off:off + cnt],
+                             self.exp_avg_sq[off:off + cnt], float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                             float(self.eps), float(self.weight_decay), int(self.step_count), float(grad_scale))
         self._has_grad = None
         ops.bump_param_epoch(self)       # in-place arena update: cached casts / packed weights of THESE parameters must refresh
         self._refresh_shadows()

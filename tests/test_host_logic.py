@@ -136,3 +136,19 @@ def test_mel_loss_rejects_wrong_shapes_before_any_launch():
         ops.mel_loss(torch.zeros(2, 1, 2000), fb, torch.zeros(2, 80, 7), n_fft=1024, hop=256)
     with pytest.raises(ValueError, match=r"\[B, 1, T\]"):
         ops.mel_loss(torch.zeros(2, 2, 2048), fb, torch.zeros(2, 80, 8), n_fft=1024, hop=256)
+
+
+def test_torch_library_operators_are_registered_and_refuse_cpu_tensors():
+    """torch.ops.mi355x_vocoder.* exists with the documented schemas; there is no CPU kernel (no fallback)."""
+    import hifigan_modified  # noqa: F401
+    from hifigan_modified import torch_ops  # noqa: F401
+    ns = torch.ops.mi355x_vocoder
+    for name in ("odconv_attn", "odconv1d", "odconv_transpose1d", "conv1d", "conv2d", "group_norm", "film", "grc_mrf_block",
+                 "generator_forward", "avg_pool1d", "mpd_fold", "disc_conv_stack", "gan_loss", "mel_loss", "mel_spectrogram",
+                 "fused_adamw_"):
+        assert hasattr(ns, name), name
+    sch = str(ns.odconv_transpose1d.default._schema)
+    assert "Tensor kernels" in sch and "int output_padding" in sch and "int fused" in sch
+    assert "Tensor(a!) p" in str(ns.fused_adamw_.default._schema)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ns.avg_pool1d(torch.randn(1, 1, 8), 2)
