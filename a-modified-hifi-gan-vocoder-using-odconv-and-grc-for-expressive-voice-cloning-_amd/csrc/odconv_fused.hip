@@ -617,9 +617,36 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
 // Short sequences with big kernel banks (the first upsampler: 33 columns per sample, 16.8 MB of banks): aggregating the
 // per-sample kernel costs more than the convolution itself.  Here the banks are used AS STORED - exactly the reference's
 // loop over k (odconv.py:187-204): D_k = W_k * x accumulates in a scratch accumulator, out += alpha[b,k] * D_k once per
-// bank.  4x the MFMA work of the aggregated form, but zero aggregation VALU and every weight fragment is loaded once
-// per S=4 samples (weights-stationary), two k-steps ahead of its use.
-template <typename T, int S, int NB, int KB>
+// bank.  4x the MFMA work of the aggregated form, but zero aggregation VALU and every weight fragment is loaded once per
+// S samples (weights-stationary), PD k-steps ahead of its use.
+// A wave owns MW M-tiles: every B fragment read from LDS feeds MW MFMAs (with one M-tile per wave the kernel issues one
+// ds_read_b128 per MFMA, which saturates the LDS array at 4 SIMDs x 4 cycles per 16-cycle MFMA).  The per-bank scratch
+// accumulators are folded into the output accumulators (out += alpha * D_k) at the end of each bank and reused.
+// fp32 storage: the x tiles are PRE-SPLIT into hi / lo bf16 planes when they are staged, weight fragments (fp32 in the packed
+// image) are split once per fragment in registers, every product is hi*hi + hi*lo + lo*hi (mfma.h).
+template <typename T> struct KlW;     // one packed A fragment of this lane: raw load + conversion to the MFMA operand
+template <> struct KlW<bf16> {
+  using R = Mma<bf16>::V;
+  static __device__ __forceinline__ R load(const char* p) { return Mma<bf16>::load_b(p); }
+  static __device__ __forceinline__ Mma<bf16>::V op(const R& r) { return r; }
+};
+template <> struct KlW<f16> {
+  using R = Mma<f16>::V;
+  static __device__ __forceinline__ R load(const char* p) { return Mma<f16>::load_b(p); }
+  static __device__ __forceinline__ Mma<f16>::V op(const R& r) { return r; }
+};
+template <> struct KlW<float> {
+  struct R { f32x4 a, b; };
+  static __device__ __forceinline__ R load(const char* p) {
+    R r; r.a = reinterpret_cast<const f32x4*>(p)[0]; r.b = reinterpret_cast<const f32x4*>(p)[1]; return r;
+  }
+  static __device__ __forceinline__ Mma<float>::V op(const R& r) {
+    const float f[8] = {r.a[0], r.a[1], r.a[2], r.a[3], r.b[0], r.b[1], r.b[2], r.b[3]};
+    return Mma<float>::split(f);
+  }
+};
+
+template <typename T, int S, int NB, int KB, int MW>
 __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                            const T* __restrict__ bias, const float* __restrict__ alpha_in,
                                                            const float* __restrict__ pooled_in, const T* __restrict__ att_w,
@@ -627,14 +654,18 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
                                                            float* __restrict__ pooled_out, OdP p) {
   using M = Mma<T>;
   using V = typename M::V;
+  using KW = KlW<T>;
   constexpr int ES = M::ES;
+  constexpr bool SPLIT = (ES == 4);
+  constexpr int LES = 2;                           // operand element size in LDS (fp32 storage: hi / lo bf16 planes)
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);
   char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
-  const int RS = lds_row_stride(p.Cin * ES, ES);
+  const int PLANE = p.Cin * LES;                   // byte offset of the lo plane inside a row (SPLIT)
+  const int RS = lds_row_stride(SPLIT ? 2 * PLANE : p.Cin * ES, LES);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const int mt = blockIdx.x * 4 + wid;
+  const int mt0 = (blockIdx.x * 4 + wid) * MW;     // first M-tile of this wave
   const int b0 = blockIdx.y * S;
   const int n_mt = p.M / 16;
   const int ZR = p.nrows - 1;                      // index of the all-zero row
@@ -665,53 +696,81 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   }
   // ---- stage the whole (short) input of every sample: row r <-> input step r + shift_lo, last row = zeros
   {
-    const int cpr = p.Cin * ES / 16;
+    const int cpr = p.Cin * ES / 16;               // 16-byte global pieces per row
     const int per = p.nrows * cpr;
-    stage_batched<8, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
-      const int s = i / per, rem = i - s * per;
-      const int r = rem / cpr, ch = rem - r * cpr;
-      const int tin = p.shift_lo + r;
-      if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
-        src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
-      dst = (s * p.nrows + r) * RS + ch * 16;
-    });
+    if constexpr (SPLIT) {
+      constexpr int UB = 8;
+      for (int i0 = tid; i0 < S * per; i0 += 256 * UB) {
+        f32x4 v[UB];
+        int d[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int i = i0 + u * 256;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          d[u] = -1;
+          if (i < S * per) {
+            const int s = i / per, rem = i - s * per;
+            const int r = rem / cpr, ch = rem - r * cpr;
+            const int tin = p.shift_lo + r;
+            d[u] = (s * p.nrows + r) * RS + ch * 8;
+            if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
+              v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (d[u] >= 0) {
+            u32x2 hi, lo;
+            Mma<float>::split4(v[u], hi, lo);
+            *reinterpret_cast<u32x2*>(xl + d[u]) = hi;
+            *reinterpret_cast<u32x2*>(xl + d[u] + PLANE) = lo;
+          }
+      }
+    } else {
+      stage_batched<8, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
+        const int s = i / per, rem = i - s * per;
+        const int r = rem / cpr, ch = rem - r * cpr;
+        const int tin = p.shift_lo + r;
+        if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
+          src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
+        dst = (s * p.nrows + r) * RS + ch * 16;
+      });
+    }
   }
   __syncthreads();
 
-  // one accumulator set PER BANK, touched only by MFMA until the end (they stay in AGPRs; at one wave per SIMD the
-  // register file has room for KB*S*NB*4 = 192 of them), then out = sum_kb alpha[b,kb] * acc[kb]
-  f32x4 acc[KB][S][NB];
+  // out = sum_kb alpha[b,kb] * D_kb; D_kb lives in `acc` while bank kb streams and is folded into `out` at the end of the bank
+  f32x4 acc[MW][S][NB], out[MW][S][NB];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
+  for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-      for (int n = 0; n < NB; ++n) acc[kb][s][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NB; ++n) { acc[mw][s][n] = f32x4{0.f, 0.f, 0.f, 0.f}; out[mw][s][n] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  const int mtc = mt < n_mt ? mt : n_mt - 1;
   const long bank_stride = (long)n_mt * p.ksteps * 512 * ES;
-  const char* wlane = reinterpret_cast<const char*>(wp) + ((long)mtc * p.ksteps * 512 + lane * 8) * ES;
-  const int total = p.K * p.ksteps;
-  // PD-deep register ring with STATIC slots (ksteps % PD == 0): one wave per SIMD has to cover L2 latency itself.
-  // The prefetch cursor (bank, k-step) advances incrementally - no integer division in the loop.
-  constexpr int PD = 8;
-  V ring[PD];
-  const char* wcur = wlane;                          // address of fragment `fetched`
-  int fetched = 0, fks = 0;
-  // the load itself is UNCONDITIONAL (past the last fragment the cursor stops and the last one is re-read): a branch around a
-  // prefetch makes the compiler wait for vmcnt(0) before every use
-  auto wnext = [&]() {
-    const V r = M::load_b(wcur);
-    if (++fetched < total) {
-      if (++fks == p.ksteps) { fks = 0; wcur += bank_stride - (long)(p.ksteps - 1) * 512 * ES; }
-      else wcur += 512 * ES;
-    }
-    return r;
-  };
+  const char* wlane[MW];
 #pragma unroll
-  for (int i = 0; i < PD; ++i) ring[i] = wnext();
+  for (int mw = 0; mw < MW; ++mw) {
+    const int mtc = (mt0 + mw) < n_mt ? (mt0 + mw) : n_mt - 1;
+    wlane[mw] = reinterpret_cast<const char*>(wp) + ((long)mtc * p.ksteps * 512 + lane * 8) * ES;
+  }
+  // PD-deep register ring with STATIC slots (ksteps % PD == 0): the wave covers the L2 latency of its weight stream itself.
+  // Everything that steers the stream is decided once per CHUNK of PD k-steps and is wave-uniform (scalar): the chunk's
+  // fragments are PD consecutive 512-element blocks of one bank, the prefetch target PD k-steps ahead is either the next chunk
+  // of this bank or the first chunk of the next bank (past the end: this chunk again, unused), and - the host checks
+  // (Cin/32) % PD == 0 - a chunk never straddles two taps, so the B-operand rows are fixed per chunk too.  Inside a chunk the
+  // k-steps differ by compile-time offsets only: no branch, no integer arithmetic per k-step (the earlier per-k-step cursor
+  // compiled to ~45 scalar / address instructions and a branch around 6 MFMAs: issue-bound at 4x the matrix-pipe time).
+  constexpr int PD = SPLIT ? 4 : 8;
+  constexpr long FRAG = 512 * ES;                   // bytes between consecutive k-step fragments of one M-tile
+  typename KW::R ring[PD][MW];
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+#pragma unroll
+    for (int mw = 0; mw < MW; ++mw) ring[j][mw] = KW::load(wlane[mw] + j * FRAG);
   // per-lane LDS byte offsets of the B operand for each of the (at most two) taps and column tiles, clamped to the zero row
-  const int cpc = p.Cin / 8;                         // multiple of 4 here: a k-step never straddles two taps
+  const int spt = p.Cin / 32;                        // k-steps per tap (multiple of PD)
   const int sample_stride = p.nrows * RS;
   unsigned lbase[2][NB];
 #pragma unroll
@@ -721,100 +780,120 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
       const int shift = p.transposed ? -tp : (tp * p.dil - p.pad);
       int r = col - p.shift_lo + n * 16 + shift;
       r = r < ZR ? r : ZR;
-      lbase[tp][n] = (unsigned)(r * RS + g * 8 * ES);
+      lbase[tp][n] = (unsigned)(r * RS + g * 8 * LES);
     }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb < p.K) {
       for (int ks0 = 0; ks0 < p.ksteps; ks0 += PD) {
+        // prefetch target of this chunk (scalar): next chunk of this bank / first chunk of the next bank / this chunk again
+        const bool last_chunk = ks0 + PD >= p.ksteps;
+        const bool last_bank = kb + 1 >= p.K;
+        const long pf_off = last_chunk ? (last_bank ? (long)kb * bank_stride + (long)ks0 * FRAG : (long)(kb + 1) * bank_stride)
+                                       : (long)kb * bank_stride + (long)(ks0 + PD) * FRAG;
+        const int tap = ks0 >= spt ? 1 : 0;
+        const unsigned koff0 = (unsigned)((ks0 - tap * spt) * 32 * LES);
+        unsigned boff[S][NB];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) boff[s][n] = (tap ? lbase[1][n] : lbase[0][n]) + (unsigned)(s * sample_stride) + koff0;
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
-          const int ks = ks0 + j;
-          const V a0 = ring[j];
-          ring[j] = wnext();
-          const int tap = (4 * ks >= cpc) ? 1 : 0;                  // wave-uniform (ntaps <= 2)
-          const unsigned koff = (unsigned)((4 * ks - tap * cpc) * 8 * ES);
+          V a0[MW];
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw) a0[mw] = KW::op(ring[j][mw]);
           // all B fragments first (independent LDS reads in flight together), then the MFMAs
           V bfr[S][NB];
 #pragma unroll
           for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
-              bfr[s][n] = M::load_b(xl + ((tap ? lbase[1][n] : lbase[0][n]) + (unsigned)(s * sample_stride) + koff));
+            for (int n = 0; n < NB; ++n) bfr[s][n] = M::load_bp(xl + boff[s][n] + j * 32 * LES, PLANE);
 #pragma unroll
           for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int n = 0; n < NB; ++n) acc[kb][s][n] = M::mma(a0, bfr[s][n], acc[kb][s][n]);
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+              for (int mw = 0; mw < MW; ++mw) acc[mw][s][n] = M::mma(a0[mw], bfr[s][n], acc[mw][s][n]);
+          // refill this ring slot for the next chunk NOW (it is consumed PD k-steps from here).  Left to itself the scheduler
+          // sinks all PD loads to the end of the chunk - right in front of their first use - and every chunk then starts by
+          // waiting out a full L2 round trip; the scheduling barrier pins the load behind this k-step's MFMAs.
+#pragma unroll
+          for (int mw = 0; mw < MW; ++mw) ring[j][mw] = KW::load(wlane[mw] + pf_off + j * FRAG);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      // fold this bank into the output accumulators and clear the scratch set
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float al = alds[s * OD_MAXK + kb];
+#pragma unroll
+        for (int mw = 0; mw < MW; ++mw)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[mw][s][n][i] += al * acc[mw][s][n][i];
+            acc[mw][s][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
       }
     }
   }
-  f32x4 out[S][NB];
-#pragma unroll
-  for (int s = 0; s < S; ++s)
-#pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      out[s][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        if (kb < p.K) {
-          const float al = alds[s * OD_MAXK + kb];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) out[s][n][i] += al * acc[kb][s][n][i];
-        }
-    }
 
-  // ---- epilogue: bias, activation -> LDS tile [s][q][64 rows] -> whole-row stores
+  // ---- epilogue: bias, activation -> LDS tile [s][q][rows of this workgroup] -> whole-row stores
   __syncthreads();
-  constexpr int RW = 64;
+  constexpr int RW = 64 * MW;
   constexpr int ORS = RW * ES + 16;
   char* ol = xl;
   const int R0 = blockIdx.x * RW;
   auto epilogue = [&](auto actf, auto pool_c) {      // one body per (activation, pooling): no per-element branch trees
     constexpr bool HAS_POOL = decltype(pool_c)::value;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const int b = b0 + s;
-      float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
-      if (mt < n_mt && b < p.B) {
-        const int row = 16 * mt + 4 * g;
-        const int r = p.transposed ? row / p.Cout : 0;
-        const int o = p.transposed ? row % p.Cout : row;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {                                   // bank biases of these 4 channels: independent 8-byte loads, then the alpha mix
-          float braw[KB][4];
+    for (int mw = 0; mw < MW; ++mw) {
+      const int mt = mt0 + mw;
 #pragma unroll
-          for (int k2 = 0; k2 < KB; ++k2) M::load4(bias + (long)(k2 < p.K ? k2 : 0) * p.Cout + o, braw[k2]);
+      for (int s = 0; s < S; ++s) {
+        const int b = b0 + s;
+        float rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mt < n_mt && b < p.B) {
+          const int row = 16 * mt + 4 * g;
+          const int r = p.transposed ? row / p.Cout : 0;
+          const int o = p.transposed ? row % p.Cout : row;
+          float bv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (bias) {                                   // bank biases of these 4 channels: independent loads, then the alpha mix
+            float braw[KB][4];
 #pragma unroll
-          for (int k2 = 0; k2 < KB; ++k2)
+            for (int k2 = 0; k2 < KB; ++k2) M::load4(bias + (long)(k2 < p.K ? k2 : 0) * p.Cout + o, braw[k2]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] += (k2 < p.K ? alds[s * OD_MAXK + k2] : 0.f) * braw[k2][i];
+            for (int k2 = 0; k2 < KB; ++k2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) bv[i] += (k2 < p.K ? alds[s * OD_MAXK + k2] : 0.f) * braw[k2][i];
+          }
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            const int q = n * 16 + col;
+            const int u = p.transposed ? q * p.stride + r - p.pad : q;
+            const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+            float ov[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              ov[i] = actf(out[mw][s][n][i] + bv[i]);
+              if (HAS_POOL && ok) rowsum[i] += M::round_store(ov[i]);
+            }
+            M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
+          }
         }
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-          const int q = n * 16 + col;
-          const int u = p.transposed ? q * p.stride + r - p.pad : q;
-          const bool ok = q < p.nq && u >= 0 && u < p.Tout;
-          float ov[4];
+        if (HAS_POOL) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            ov[i] = actf(out[s][n][i] + bv[i]);
-            if (HAS_POOL && ok) rowsum[i] += M::round_store(ov[i]);
+            float v = rowsum[i];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+            rowsum[i] = v;
           }
-          M::store4(ol + ((long)(s * NB * 16 + n * 16 + col)) * ORS + (row - R0) * ES, ov);
-        }
-      }
-      if (HAS_POOL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = rowsum[i];
-#pragma unroll
-          for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-          rowsum[i] = v;
-        }
-        if (col == 0 && mt < n_mt && b < p.B) {   // the K-loop kernel covers a sample's columns in one workgroup: one slot
-          const int row = 16 * mt + 4 * g;
-          *reinterpret_cast<f32x4*>(pooled_out + (long)b * p.M + row) = f32x4{rowsum[0], rowsum[1], rowsum[2], rowsum[3]};
+          if (col == 0 && mt < n_mt && b < p.B) {   // the K-loop kernel covers a sample's columns in one workgroup: one slot
+            const int row = 16 * mt + 4 * g;
+            *reinterpret_cast<f32x4*>(pooled_out + (long)b * p.M + row) = f32x4{rowsum[0], rowsum[1], rowsum[2], rowsum[3]};
+          }
         }
       }
     }
@@ -845,26 +924,27 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int S, int NB>
+template <typename T, int S, int NB, int MW>
 static int od_kloop_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in,
                            const void* att_w, const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream,
                            int* slots_out) {
   using M = Mma<T>;
-  if (p.nq > NB * 16 || p.K > 4 || p.Cin % 32 || p.ksteps % 8 || p.nchunks != 4 * p.ksteps || p.ntaps > 2)
+  constexpr int PD = M::ES == 4 ? 4 : 8;
+  if (p.nq > NB * 16 || p.K > 4 || p.Cin % 32 || (p.Cin / 32) % PD || p.ksteps % PD || p.nchunks != 4 * p.ksteps || p.ntaps > 2)
     return MV_ERR_UNSUPPORTED;
   // rows: every input step that any column can touch (shift_lo .. Tin-1 shifted) + one zero row
   p.nrows = p.Tin - p.shift_lo + 1;
-  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
-  const size_t obytes = (size_t)S * NB * 16 * (64 * M::ES + 16);
+  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(M::ES == 4 ? 4 * p.Cin : p.Cin * M::ES, 2);
+  const size_t obytes = (size_t)S * NB * 16 * (64 * MW * M::ES + 16);
   const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = odconv_kloop_kernel<T, S, NB, 4>;
+  auto kern = odconv_kloop_kernel<T, S, NB, 4, MW>;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set = lds;
   }
-  dim3 grid(cdiv(p.M / 16, 4), cdiv(p.B, S));
+  dim3 grid(cdiv(p.M / 16, 4 * MW), cdiv(p.B, S));
   if (grid.y > 65535) return MV_ERR_UNSUPPORTED;
   if (slots_out) { *slots_out = 1; return MV_OK; }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
@@ -1001,10 +1081,21 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
   MV_DISPATCH(dtype, {
     if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler)
       rc = MV_ERR_UNSUPPORTED;
-      if (!film_proj && dtype != MV_F32 && wbytes > (4 << 20) && B >= 2)   // K-loop, weights-stationary over S samples
-      {   // S = 2 measured best (two workgroups per CU overlap each other's LDS/L2 latency); S = 1 if the tiles do not fit
-        rc = od_kloop_launch<T, 2, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
-        if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+      if (!film_proj && wbytes > (4 << 20) && B >= 2)   // K-loop, weights-stationary over S samples
+      {   // S = 2 measured best; S = 1 if the tiles do not fit.  MV_KLOOP_MW selects the M-tiles per wave (A/B measurements)
+        // measured at ups0 (C2): 16-bit 41.5 us with one M-tile per wave (two workgroups per CU) vs 43.8 with two; fp32 (split
+        // operands, 3 MFMAs per product) 97 us with two M-tiles per wave vs 133 with one.  The launch is bound by the weight
+        // stream out of L2 (16 sample groups x 16.8 MB = 268 MB), not by the matrix pipe (12 us) - see DESIGN.md
+        static int kmw = -1;
+        if (kmw < 0) { const char* e = getenv("MV_KLOOP_MW"); kmw = e ? atoi(e) : 0; }
+        const int mw_sel = kmw ? kmw : (dtype == MV_F32 ? 2 : 1);
+        if (mw_sel == 2) {
+          rc = od_kloop_launch<T, 2, 3, 2>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+          if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3, 2>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        } else {
+          rc = od_kloop_launch<T, 2, 3, 1>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+          if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3, 1>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        }
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(2, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
