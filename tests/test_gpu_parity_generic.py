@@ -376,9 +376,19 @@ def test_plain_hifigan_v3_vs_cpu_restatement(H, dtype, tol, Tm):
     torch.manual_seed(1)
     mel = torch.randn(1, 80, Tm)
     ref = O.plain_hifigan_forward(mel, sd)
-    y = g.cuda().to(dtype).train(False)(mel.cuda().to(dtype))
+    g = g.cuda().to(dtype).train(False)
+    y = g(mel.cuda().to(dtype))
     assert y.shape == (1, 1, Tm * 256) and y.dtype == dtype
     assert O.rel_l2(y.float().cpu(), ref) < tol
+    assert g.fused_supported()                                         # every conv ran on the fused channels-last MFMA kernel
+    assert O.rel_l2(g(mel.cuda().to(dtype), force_generic=True).float().cpu(), ref) < tol     # and the generic NCT path agrees too
+    # the captured forward (what bench.py times) replays to the same waveform, also on new input in the static buffer
+    replay = g.graphed(mel.cuda().to(dtype))
+    assert torch.equal(replay(), y)
+    torch.manual_seed(2)
+    mel2 = torch.randn(1, 80, Tm)
+    replay.mel.copy_(mel2.cuda().to(dtype))
+    assert O.rel_l2(replay().float().cpu(), O.plain_hifigan_forward(mel2, sd)) < tol
 
 
 def test_full_c2_batch_properties(H):
