@@ -229,10 +229,13 @@ def test_pack_cache_follows_each_optimizer_separately():
     assert not torch.equal(y0, y1)                         # the D update is visible through the cache
     assert torch.equal(y1, fresh())                        # and equals a from-scratch pack
     n_entries = len(disc_fused._packs.d)
-    tr.generator_optimizer.zero_grad()
-    tr.generator_optimizer.step()                          # G-only update (zero grads: weight decay still moves G)
+    def zero_grads(opt):                                   # explicit zero gradients (a None gradient leaves a parameter untouched,
+        for p in opt.params:                               # like torch.optim.AdamW): weight decay alone then moves the weights
+            p.grad = torch.zeros_like(p)
+    zero_grads(tr.generator_optimizer)
+    tr.generator_optimizer.step()                          # G-only update
     assert torch.equal(d_out(), y1) and len(disc_fused._packs.d) == n_entries
-    tr.discriminator_optimizer.zero_grad()
+    zero_grads(tr.discriminator_optimizer)
     tr.discriminator_optimizer.step()                      # D-only update (weight decay)
     y2 = d_out()
     assert not torch.equal(y2, y1) and torch.equal(y2, fresh())
