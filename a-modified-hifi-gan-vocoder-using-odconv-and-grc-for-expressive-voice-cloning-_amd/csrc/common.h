@@ -112,6 +112,10 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
     default: return MV_ERR_DTYPE;                                       \
   }
 
+// internal cross-file entry (conv_out.hip), not part of the C ABI
+int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
+                        int pad, int act, int dtype, hipStream_t stream);
+
 #define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
 // runtime calls that are not kernel launches: propagate the hipError_t as the entry point's (positive) return code
 #define MV_HIP(call) do { const hipError_t mv_e_ = (call); if (mv_e_ != hipSuccess) return (int)mv_e_; } while (0)

@@ -44,6 +44,71 @@ __global__ __launch_bounds__(256) void conv_out_tanh_kernel(const T* __restrict_
   if (t < Tn) st<T>(y + (size_t)b * Tn + t, apply_act((acc0 + acc1) + (acc2 + acc3), act, 0.f));
 }
 
+// The same output convolution fed by the LAST block of an MRF chain (mrf_fused.hip): the input row is formed on the way into LDS as
+// a[b][c] * f + b[b][c] + x  (that block's GroupNorm(8,64) + residual add, deferred), so the block's output never makes a round
+// trip through HBM.  ab = fp32 [B][2][C].
+template <typename T, int C>
+__global__ __launch_bounds__(256) void conv_out_affine_kernel(const T* __restrict__ f, const T* __restrict__ x,
+                                                              const float* __restrict__ ab, const float* __restrict__ w, float bias,
+                                                              T* __restrict__ y, int Tn, int ks, int pad, int act) {
+  using M = Mma<T>;
+  constexpr int ES = M::ES;
+  constexpr int RS = C * ES + 16;
+  constexpr int CPR = C * ES / 16, EPC = 16 / ES;
+  extern __shared__ __align__(16) char lds[];
+  const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+  const int rows = 256 + ks - 1;
+  const T* xb = x + (size_t)b * Tn * C;
+  const T* fb = f + (size_t)b * Tn * C;
+  // a thread keeps its 16-byte column (256 % CPR == 0): its EPC channels' affine stays in registers
+  static_assert(256 % CPR == 0, "fixed column per thread");
+  const int ch = tid % CPR;
+  float ra[EPC], rb[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) { ra[j] = ab[(size_t)b * 2 * C + ch * EPC + j]; rb[j] = ab[(size_t)b * 2 * C + C + ch * EPC + j]; }
+  constexpr int UB = 6;
+  for (int r0 = tid / CPR; r0 < rows; r0 += (256 / CPR) * UB) {
+    alignas(16) T xv[UB][EPC];
+    alignas(16) T fv[UB][EPC];
+    bool ok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + u * (256 / CPR), t = t0 - pad + r;
+      ok[u] = r < rows && t >= 0 && t < Tn;
+      const size_t off = (size_t)(ok[u] ? t : 0) * C + ch * EPC;
+      *reinterpret_cast<uint4*>(xv[u]) = *reinterpret_cast<const uint4*>(xb + off);
+      *reinterpret_cast<uint4*>(fv[u]) = *reinterpret_cast<const uint4*>(fb + off);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + u * (256 / CPR);
+      if (r < rows) {
+        alignas(16) T o[EPC];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) st<T>(o + j, ok[u] ? ra[j] * ld<T>(fv[u] + j) + rb[j] + ld<T>(xv[u] + j) : 0.f);
+        *reinterpret_cast<uint4*>(lds + (size_t)r * RS + ch * 16) = *reinterpret_cast<const uint4*>(o);
+      }
+    }
+  }
+  __syncthreads();
+  float acc0 = bias, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  for (int j = 0; j < ks; ++j) {
+    const char* row = lds + (size_t)(tid + j) * RS;
+    const float* wj = w + j * C;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+      float xq[4];
+      M::load4(row + c * ES, xq);
+      acc0 += wj[c] * xq[0];
+      acc1 += wj[c + 1] * xq[1];
+      acc2 += wj[c + 2] * xq[2];
+      acc3 += wj[c + 3] * xq[3];
+    }
+  }
+  const int t = t0 + tid;
+  if (t < Tn) st<T>(y + (size_t)b * Tn + t, apply_act((acc0 + acc1) + (acc2 + acc3), act, 0.f));
+}
+
 // w_t[j][c] = w[0][c][j] as fp32 (tiny)
 template <typename P>
 __global__ void conv_out_pack_kernel(const P* __restrict__ w, float* __restrict__ wt, int C, int ks) {
@@ -118,6 +183,22 @@ __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restri
 }  // namespace mv
 
 using namespace mv;
+
+// internal (not part of the C ABI): used by the MRF chain's fused ending, mrf_fused.hip
+int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
+                        int pad, int act, int dtype, hipStream_t stream) {
+  if (C != 64 || 2 * pad != ks - 1) return MV_ERR_UNSUPPORTED;
+  dim3 grid(cdiv(T_, 256), B);
+  MV_DISPATCH(dtype, {
+    const size_t lds = (size_t)(256 + ks - 1) * (64 * Mma<T>::ES + 16);
+    if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+    auto kern = conv_out_affine_kernel<T, 64>;
+    static size_t lds_set = 0;
+    if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)f, (const T*)x, ab, wt, bias, (T*)y, T_, ks, pad, act);
+  });
+  return MV_OK;
+}
 
 extern "C" int mv_conv_out_pack(const void* w, int param_dtype, float* wt, int C, int ks, void* stream) {
   MV_CHECK_ARG(w && wt && C > 0 && ks > 0);

@@ -15,6 +15,15 @@
 // 3 reads + 1 write of the stream = 4 x 33.5 MB per block at C2 (algorithmic minimum 2 x 33.5 MB).
 // Partial sums are written per workgroup and summed in a fixed order by the consumer: deterministic, no atomics.
 //
+// CHAIN (mv_mrf_chain_fwd_cl, the generator's three blocks in a row).  The per-block form recomputes stages 1-3 in its third
+// pass only to apply GN8, an affine per (sample, channel).  The chain defers that affine to the NEXT block's first pass:
+//   pass B (PASS 5) of block i:   x_i -> stages 1-3 ONCE -> writes f_i (pre-GroupNorm fusion output) + partial sums of f_i
+//   pass A (PASS 4) of block i+1: x_{i+1} = a_i * f_i + b_i + x_i formed while the tile is committed to LDS (a_i, b_i from the GN8
+//                                 statistics and affine of block i), written out once, stage 1 on it -> partial sums of v_{i+1}
+//   pass F (PASS 6) after the last block materialises its output the same way.
+// Per block: 320 MFMAs per 64-step tile instead of 512, one SiLU pass instead of two, two launches instead of three; 5 stream
+// transfers (A: read f, read x, write x'; B: read x', write f) instead of 4.  Block 0's pass A is the plain statistics pass (PASS 1).
+//
 // Workgroup = NWAVES waves, each wave owns NTW*16 consecutive time steps of one sample and stages its own
 // x tile (+halo) into a private LDS region (no block barrier on the data path); packed weights (48 KB) are
 // staged once per workgroup.
@@ -177,6 +186,38 @@ static inline bool mrf_meta_is_std(const MrfMeta& m) {
 
 constexpr int MRF_HMAX = 8;   // largest dilation the fused kernel accepts (prefetch registers are sized for it)
 
+// one 16-byte chunk of storage elements <-> floats (8 for 16-bit storage, 4 for fp32)
+template <typename T> struct Chunk;
+template <> struct Chunk<bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_lo(u[i]); f[2 * i + 1] = bf16_hi(u[i]); }
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    return u32x4{pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7])};
+  }
+};
+template <> struct Chunk<f16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+    const f16x8_t h = __builtin_bit_cast(f16x8_t, u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) {
+    return u32x4{pack_f16(f[0], f[1]), pack_f16(f[2], f[3]), pack_f16(f[4], f[5]), pack_f16(f[6], f[7])};
+  }
+};
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const u32x4& u, float* f) {
+    const f32x4 v = __builtin_bit_cast(f32x4, u);
+    f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+  }
+  static __device__ __forceinline__ u32x4 pack(const float* f) { return __builtin_bit_cast(u32x4, f32x4{f[0], f[1], f[2], f[3]}); }
+};
+
 #ifdef MV_MRF_TIMING
 __device__ long long* mrf_dbg = nullptr;
 #endif
@@ -186,9 +227,18 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
                                                           const float* __restrict__ part5, float* __restrict__ part5_out,
                                                           const float* __restrict__ part8, float* __restrict__ part8_out,
                                                           const uint8_t* __restrict__ mask, float mask_scale,
-                                                          int Tn, int nwg, int nit, float eps) {
+                                                          int Tn, int nwg, int nit, float eps,
+                                                          const T* __restrict__ fprev, const char* __restrict__ packed_prev) {
   using M = Mma<T>;
   using V = typename M::V;
+  // PASS 1/2/3: the per-block passes (statistics of v, statistics of f, output).  Chain passes: 4 = A (tile rows are
+  // a*fprev + b + x, written to `out`; statistics of v), 5 = B (writes f to `out`; statistics of f), 6 = F (rows as in A, write only)
+  constexpr bool RECON = (PASS == 4 || PASS == 6);
+  constexpr bool NEED5 = (PASS == 2 || PASS == 3 || PASS == 5);
+  constexpr bool NEED8 = (PASS == 3 || RECON);
+  constexpr bool STATS_V = (PASS == 1 || PASS == 4);
+  constexpr bool STATS_F = (PASS == 2 || PASS == 5);
+  constexpr bool NEED_W = (PASS != 6);
   constexpr int ES = M::ES;                           // storage element size in HBM
   constexpr int FS = M::NSETS * FRAG_BYTES;
   // LDS tile rows hold MFMA operands: 16-bit storage as stored; fp32 storage PRE-SPLIT into a hi and a lo bf16 plane per row
@@ -200,7 +250,15 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   constexpr int WBYTES = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
   constexpr int TW = NTW * 16;                        // time steps per wave and iteration
   constexpr int CH = MRF_C * ES / 16;                 // 16-byte chunks per row
-  constexpr int NLD = ((TW + 2 * MRF_HMAX) * CH + 63) / 64;   // prefetch registers (u32x4) per lane
+  // 16-bit storage: every wave stages a PRIVATE tile (TW + 2 halo rows; no workgroup barrier on the data path).  fp32 storage
+  // (split operands: 2x the LDS bytes per row, 16-step tiles) shares ONE tile of NWAVES*TW + 2 halo rows per workgroup instead:
+  // with private tiles 26 rows were loaded, combined and split per 16 output steps (62 % halo overhead, every wave redoing its
+  // neighbours' rows); shared it is 138 rows per 128 steps, staged cooperatively between two workgroup barriers per tile, and
+  // the outputs leave straight from the accumulators (no staging in rows that neighbours still read as halo).
+  constexpr bool SHARED = SPLIT;
+  constexpr int NT = NWAVES * 64;
+  constexpr int NLD = SHARED ? ((NWAVES * TW + 2 * MRF_HMAX) * CH + NT - 1) / NT
+                             : ((TW + 2 * MRF_HMAX) * CH + 63) / 64;   // prefetch registers (u32x4) per lane
 
   extern __shared__ __align__(16) char lds[];
   char* wl = lds;                                           // packed weights
@@ -221,39 +279,68 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #else
 #define MRF_TM() do {} while (0)
 #endif
-  const int rows = TW + 2 * H;
-  char* xw = xl + (size_t)wid * rows * RS;
+  const int rows = (SHARED ? NWAVES * TW : TW) + 2 * H;                  // rows of one staged tile
+  char* xw = xl + (size_t)wid * (SHARED ? TW : rows) * RS;              // row 0 of this wave's window (its first halo row)
+  char* xs = SHARED ? xl : xw;                                           // base of the tile this thread helps to stage
+  const int sidx = SHARED ? tid : lane;                                  // staging piece index of this thread: sidx + SSTEP * i
+  constexpr int SSTEP = SHARED ? NT : 64;
+  const int own_rows = SHARED ? NWAVES * TW : TW;
   const T* xb = x + (size_t)b * Tn * MRF_C;
 
   // ---- software pipeline: the NEXT tile's rows travel HBM -> registers while the current tile is computed
-  u32x4 pre[NLD];
-  auto tile_t0 = [&](int it) { return ((wg * nit + it) * NWAVES + wid) * TW; };
+  using CK = Chunk<T>;
+  constexpr int NPF = RECON ? NLD : 1;
+  u32x4 pre[NLD], pref[NPF];                         // x rows; chain passes A / F: the previous block's f rows as well
+  const T* fb = RECON ? fprev + (size_t)b * Tn * MRF_C : nullptr;
+  T* ob = out + (size_t)b * Tn * MRF_C;
+  float ra[CK::N], rb[CK::N];                        // chain passes A / F: this lane's chunk of the deferred GN8 affine (set below)
+  auto tile_t0 = [&](int it) { return ((wg * nit + it) * NWAVES + wid) * TW; };     // first output step of this WAVE
+  auto stage_t0 = [&](int it) { return SHARED ? (wg * nit + it) * NWAVES * TW : tile_t0(it); };   // ... of the staged tile
   auto issue = [&](int it) {
-    const int t0 = tile_t0(it);
+    const int t0 = stage_t0(it);
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = lane + 64 * i;
+      const int idx = sidx + SSTEP * i;
       const int r = idx / CH, ch = idx % CH;
       const int t = t0 - H + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < rows * CH && t >= 0 && t < Tn)
+      u32x4 v = {0u, 0u, 0u, 0u}, vf = {0u, 0u, 0u, 0u};
+      if (idx < rows * CH && t >= 0 && t < Tn) {
         v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(xb + (size_t)t * MRF_C) + ch * 16);
+        if constexpr (RECON) vf = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(fb + (size_t)t * MRF_C) + ch * 16);
+      }
       pre[i] = v;
+      if constexpr (RECON) pref[i] = vf;
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int idx = lane + 64 * i;
-      const int r = idx / CH, ch = idx % CH;
+      const int idx = sidx + SSTEP * i;
+      const int r = idx / CH, ch = idx % CH;           // ch == lane % CH for every i (SSTEP % CH == 0): ra / rb are per lane
       if (idx < rows * CH) {
-        if constexpr (SPLIT) {
-          u32x2 hi, lo;
-          M::split4(__builtin_bit_cast(f32x4, pre[i]), hi, lo);
-          *reinterpret_cast<u32x2*>(xw + r * RS + ch * 8) = hi;
-          *reinterpret_cast<u32x2*>(xw + r * RS + PLANE + ch * 8) = lo;
-        } else {
-          *reinterpret_cast<u32x4*>(xw + r * RS + ch * 16) = pre[i];
+        u32x4 val = pre[i];
+        if constexpr (RECON) {
+          // x' = a * f + b + x: the previous block's GroupNorm(8,64) + residual (grc_lora.py:161-163), applied on the way in
+          const int t = t0 - H + r;
+          float fx[CK::N], ff[CK::N];
+          CK::unpack(pre[i], fx);
+          CK::unpack(pref[i], ff);
+          const bool inside = t >= 0 && t < Tn;         // rows outside the sample are the conv's zero padding, not b
+#pragma unroll
+          for (int j = 0; j < CK::N; ++j) fx[j] = inside ? ra[j] * ff[j] + rb[j] + fx[j] : 0.f;
+          val = CK::pack(fx);
+          if (r >= H && r < H + own_rows && inside)      // the tile's own (non-halo) rows leave for HBM here, once
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + ch * 16) = val;
+        }
+        if constexpr (PASS != 6) {
+          if constexpr (SPLIT) {
+            u32x2 hi, lo;
+            M::split4(__builtin_bit_cast(f32x4, val), hi, lo);
+            *reinterpret_cast<u32x2*>(xs + r * RS + ch * 8) = hi;
+            *reinterpret_cast<u32x2*>(xs + r * RS + PLANE + ch * 8) = lo;
+          } else {
+            *reinterpret_cast<u32x4*>(xs + r * RS + ch * 16) = val;
+          }
         }
       }
     }
@@ -267,32 +354,36 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     const u32x4* src = reinterpret_cast<const u32x4*>(packed);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
     u32x4 wv[PER];
+    if constexpr (NEED_W) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = tid + i * NWAVES * 64;
-      wv[i] = src[idx < N16 ? idx : N16 - 1];
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * NWAVES * 64;
+        wv[i] = src[idx < N16 ? idx : N16 - 1];
+      }
     }
     // GroupNorm statistics from the previous passes' partial sums: one partial per thread, then a fixed-order sum in LDS
     float2 pp = {0.f, 0.f};
     const int pi = tid >> 4, pq = tid & 15;                 // (workgroup index, group) for GN5; GN8 uses threads 256..
-    if (PASS >= 2 && pi < nwg && tid < 256) pp = *reinterpret_cast<const float2*>(part5 + ((size_t)(b * nwg + pi) * 16 + pq) * 2);
+    if (NEED5 && pi < nwg && tid < 256) pp = *reinterpret_cast<const float2*>(part5 + ((size_t)(b * nwg + pi) * 16 + pq) * 2);
     float2 pp8 = {0.f, 0.f};
     const int t8 = tid - 256, pi8 = t8 >> 3, pq8 = t8 & 7;
-    if (PASS >= 3 && NWAVES * 64 >= 512 && t8 >= 0 && pi8 < nwg && t8 < 128) pp8 = *reinterpret_cast<const float2*>(part8 + ((size_t)(b * nwg + pi8) * 8 + pq8) * 2);
+    if (NEED8 && NWAVES * 64 >= 512 && t8 >= 0 && pi8 < nwg && t8 < 128) pp8 = *reinterpret_cast<const float2*>(part8 + ((size_t)(b * nwg + pi8) * 8 + pq8) * 2);
+    if constexpr (NEED_W) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int idx = tid + i * NWAVES * 64;
-      if (idx < N16) dst[idx] = wv[i];
+      for (int i = 0; i < PER; ++i) {
+        const int idx = tid + i * NWAVES * 64;
+        if (idx < N16) dst[idx] = wv[i];
+      }
     }
     // xl (the waves' x tiles) is not written before the first commit(): use its head as scratch for the partials
     float2* sc5 = reinterpret_cast<float2*>(xl);
     float2* sc8 = sc5 + 256;
-    if (PASS >= 2 && tid < 256) sc5[tid] = pp;
-    if (PASS >= 3 && NWAVES * 64 >= 512 && t8 >= 0 && t8 < 128) sc8[t8] = pp8;
+    if (NEED5 && tid < 256) sc5[tid] = pp;
+    if (NEED8 && NWAVES * 64 >= 512 && t8 >= 0 && t8 < 128) sc8[t8] = pp8;
   }
   const bool fast_stats = nwg <= 16 && NWAVES * 64 >= 512;
-  if (PASS >= 2) __syncthreads();
-  if (PASS >= 2 && tid < 16) {
+  if (NEED5 || NEED8) __syncthreads();
+  if (NEED5 && tid < 16) {
     float s1 = 0.f, s2 = 0.f;
     if (fast_stats) {
       const float2* sc5 = reinterpret_cast<const float2*>(xl);
@@ -308,7 +399,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     st5[tid * 2] = mu;
     st5[tid * 2 + 1] = rsqrtf(var + eps);
   }
-  if (PASS >= 3 && tid >= 64 && tid < 72) {
+  if (NEED8 && tid >= 64 && tid < 72) {
     const int q = tid - 64;
     float s1 = 0.f, s2 = 0.f;
     if (fast_stats) {
@@ -331,16 +422,28 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   const float* b_conv = tab, *b_res = tab + 64, *b_fus = tab + 128;
   const float* g5 = tab + 192, *be5 = tab + 256, *g8 = tab + 320, *be8 = tab + 384;
   const char* xcol = xw + (size_t)(col + H) * RS + 8 * g * LES;  // this lane's B-operand base
-  T* ob = out + (size_t)b * Tn * MRF_C;
+  if constexpr (RECON) {
+    // deferred GroupNorm(8,64) of the PREVIOUS block for this lane's chunk of channels: a = rstd * gamma, b = beta - mean * a
+    const float* tprev = reinterpret_cast<const float*>(packed_prev + WBYTES);
+    const int c0 = (lane % CH) * CK::N;
+#pragma unroll
+    for (int j = 0; j < CK::N; ++j) {
+      const int c = c0 + j, q = c >> 3;
+      ra[j] = st8[q * 2 + 1] * tprev[320 + c];
+      rb[j] = tprev[384 + c] - st8[q * 2] * ra[j];
+    }
+  }
 
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // statistics partials (passes 1, 2)
 
   for (int it = 0; it < nit; ++it) {
     const int t0 = tile_t0(it);
-    commit();                       // this tile: registers -> this wave's private LDS region
+    if constexpr (SHARED && PASS != 6) { if (it > 0) __syncthreads(); }   // every wave is done reading the previous shared tile
+    commit(stage_t0(it));           // this tile: registers -> LDS (chain A / F: + x' -> HBM)
     MRF_TM();
     if (it + 1 < nit) issue(it + 1);
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (PASS == 6) continue;
+    if constexpr (SHARED) __syncthreads(); else __builtin_amdgcn_wave_barrier();
 
     // ---- stage 1: v[cc][t] = b_eff + sum_{tap,c} W_eff[cc][tap][c] x[t+off(tap)][c]
     f32x4 v[4][NTW];
@@ -398,7 +501,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
 
     MRF_TM();
-    if (PASS == 1) {
+    if (STATS_V) {
       // partial sums of v per GN(5,20) group: concat rows 16m+4g..+3 are exactly group 4m+g
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -465,7 +568,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
 
     MRF_TM();
-    if (PASS == 2) {
+    if (STATS_F) {
       // partial sums of f per GN(8,64) group: rows 16m+4g+r -> group 2m + (g>>1)
 #pragma unroll
       for (int m = 0; m < 4; ++m)
@@ -475,7 +578,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float q = ok ? f[m][n][r] : 0.f; s1[m] += q; s2[m] += q * q; }
         }
-      continue;
+      if constexpr (PASS == 2) continue;
+    }
+
+    if constexpr (PASS == 5) {
+      // chain pass B: f itself leaves for HBM (its GroupNorm is applied by the next block's pass A); staged in this wave's tile rows
+      // (the x tile is dead: its last reader was the residual 1x1 above) and streamed out as whole rows like the output below
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+          const float o[4] = {f[m][n][0], f[m][n][1], f[m][n][2], f[m][n][3]};
+          if constexpr (SHARED) {     // straight from the accumulators: 4 channels x fp32 = 16 B per lane, 64 B runs per row
+            const int t = t0 + n * 16 + col;
+            if (t < Tn) M::store4(ob + (size_t)t * MRF_C + 16 * m + 4 * g, o);
+          } else {
+            M::store4(xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES, o);
+          }
+        }
     }
 
     // ---- stage 4 (pass 3): out = GN8(f) * keep/(1-p) + x, written IN PLACE over this wave's x tile, then streamed
@@ -526,21 +646,24 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
           for (int n = 0; n < NTW; ++n) {
             const float o[4] = {f[m][n][0], f[m][n][1], f[m][n][2], f[m][n][3]};
-            M::store4(xw + (size_t)(n * 16 + col + H) * RS + (16 * m + 4 * g) * ES, o);
+            const int t = t0 + n * 16 + col;
+            if (t < Tn) M::store4(ob + (size_t)t * MRF_C + 16 * m + 4 * g, o);     // shared tile: straight to HBM
           }
       }
     };
-    if (mask) stage4(std::true_type{}); else stage4(std::false_type{});
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (PASS == 3) { if (mask) stage4(std::true_type{}); else stage4(std::false_type{}); }
+    if constexpr (!SHARED) {
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < (TW * CH) / 64; ++i) {
-      const int idx = lane + 64 * i;
-      const int r = idx / CH, ch = idx % CH;
-      const int t = t0 + r;
-      const u32x4 val = *reinterpret_cast<const u32x4*>(xw + (size_t)(r + H) * RS + ch * 16);
-      if (t < Tn) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + ch * 16) = val;
+      for (int i = 0; i < (TW * CH) / 64; ++i) {
+        const int idx = lane + 64 * i;
+        const int r = idx / CH, ch = idx % CH;
+        const int t = t0 + r;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(xw + (size_t)(r + H) * RS + ch * 16);
+        if (t < Tn) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(ob + (size_t)t * MRF_C) + ch * 16) = val;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
     MRF_TM();
   }
 #ifdef MV_MRF_TIMING
@@ -551,7 +674,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   }
 #endif
 
-  if (PASS == 1) {
+  if (STATS_V) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -568,7 +691,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
       part5_out[(size_t)(b * nwg + wg) * 32 + tid] = a;
     }
   }
-  if (PASS == 2) {
+  if (STATS_F) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
 #pragma unroll
@@ -604,8 +727,9 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
   constexpr int RS = (M::ES == 4 ? 2 * MRF_C * 2 : MRF_C * M::ES) + 32;   // as in the kernel
   int nwg, nit;
   mrf_geometry(B, Tn, NWAVES * NTW * 16, &nwg, &nit);
+  const size_t tile_rows = M::ES == 4 ? (size_t)NWAVES * NTW * 16 + 2 * meta.halo : (size_t)NWAVES * (NTW * 16 + 2 * meta.halo);
   const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
-                     (size_t)NWAVES * 32 * 4 + (size_t)NWAVES * (NTW * 16 + 2 * meta.halo) * RS;
+                     (size_t)NWAVES * 32 * 4 + tile_rows * RS;
   if (lds > 160 * 1024 || meta.halo > MRF_HMAX) return MV_ERR_UNSUPPORTED;
   float* part5 = ws;
   float* part8 = ws + (size_t)B * nwg * 32;
@@ -613,7 +737,7 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
 #ifdef MV_MRF_TIMING
   static long long* dbg = nullptr;
   static int calls = 0;
-  if (!dbg) { hipMalloc(&dbg, 3 * 65536 * 12 * 8); hipMemset(dbg, 0xff, 3 * 65536 * 12 * 8); hipMemcpyToSymbol(HIP_SYMBOL(mrf_dbg), &dbg, sizeof(dbg)); }
+  if (!dbg) { hipMalloc(&dbg, 6 * 65536 * 12 * 8); hipMemset(dbg, 0xff, 6 * 65536 * 12 * 8); hipMemcpyToSymbol(HIP_SYMBOL(mrf_dbg), &dbg, sizeof(dbg)); }
 #endif
   const bool stdm = mrf_meta_is_std(meta);
   auto k1 = stdm ? mrf_kernel<T, NWAVES, NTW, 1, true> : mrf_kernel<T, NWAVES, NTW, 1, false>;
@@ -627,11 +751,11 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
     lds_set[stdm] = lds;
   }
   hipLaunchKernelGGL(k1, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, nullptr, part5,
-                     nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps);
+                     nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
   hipLaunchKernelGGL(k2, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps);
+                     nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
   hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps);
+                     part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
 #ifdef MV_MRF_TIMING
   if (++calls == 40) {
     hipStreamSynchronize(stream);
@@ -647,6 +771,93 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
     }
   }
 #endif
+  return MV_OK;
+}
+
+// ---- the chained form: blocks 0..n-1 in a row, GroupNorm(8,64) of block i deferred into pass A of block i+1 (header comment)
+static inline size_t mrf_act_bytes(int B, int Tn, size_t es) { return (((size_t)B * Tn * MRF_C * es) + 255) / 256 * 256; }
+
+template <typename T, int NWAVES, int NTW, int PASS>
+static void mrf_chain_pass(bool stdm, dim3 grid, size_t lds, hipStream_t stream, const T* x, T* out, const char* packed,
+                           const MrfMeta& meta, const float* p5, float* p5o, const float* p8, float* p8o, int Tn, int nwg, int nit,
+                           float eps, const T* fprev, const char* packed_prev) {
+  auto k = stdm ? mrf_kernel<T, NWAVES, NTW, PASS, true> : mrf_kernel<T, NWAVES, NTW, PASS, false>;
+  static size_t lds_set[2] = {0, 0};
+  if (lds > lds_set[stdm]) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set[stdm] = lds;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(NWAVES * 64), lds, stream, x, out, packed, meta, p5, p5o, p8, p8o, (const uint8_t*)nullptr, 1.f, Tn,
+                     nwg, nit, eps, fprev, packed_prev);
+}
+
+// deferred GroupNorm(8,64) affine of the chain's last block, for a consumer that applies it itself: ab[b][0][c] = rstd * gamma,
+// ab[b][1][c] = beta - mean * rstd * gamma (fixed-order sum of the per-workgroup partials)
+__global__ __launch_bounds__(64) void mrf_affine_kernel(const float* __restrict__ part8, const float* __restrict__ tab,
+                                                        float* __restrict__ ab, int nwg, int Tn, float eps) {
+  const int b = blockIdx.x, c = threadIdx.x, q = c >> 3;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = 0; i < nwg; ++i) {
+    s1 += part8[((size_t)(b * nwg + i) * 8 + q) * 2];
+    s2 += part8[((size_t)(b * nwg + i) * 8 + q) * 2 + 1];
+  }
+  const float n = 8.f * (float)Tn, mu = s1 / n;
+  const float rs = rsqrtf(fmaxf(s2 / n - mu * mu, 0.f) + eps);
+  const float a = rs * tab[320 + c];
+  ab[(size_t)b * 128 + c] = a;
+  ab[(size_t)b * 128 + 64 + c] = tab[384 + c] - mu * a;
+}
+
+// `ab_out` non-null: no pass F; the caller gets the last block's (f, x) buffers and its deferred affine instead
+template <typename T, int NWAVES, int NTW>
+static int mrf_chain_launch(const void* x, void* out, const void* const* packed, const MrfMeta* metas, int nblocks, char* ws,
+                            int B, int Tn, float eps, hipStream_t stream, float* ab_out = nullptr, const void** f_last = nullptr,
+                            const void** x_last = nullptr) {
+  using M = Mma<T>;
+  constexpr int FS = M::NSETS * FRAG_BYTES;
+  constexpr int RS = (M::ES == 4 ? 2 * MRF_C * 2 : MRF_C * M::ES) + 32;   // as in the kernel
+  int nwg, nit, hmax = 0;
+  mrf_geometry(B, Tn, NWAVES * NTW * 16, &nwg, &nit);
+  for (int i = 0; i < nblocks; ++i) hmax = metas[i].halo > hmax ? metas[i].halo : hmax;
+  const size_t tile_rows = M::ES == 4 ? (size_t)NWAVES * NTW * 16 + 2 * hmax : (size_t)NWAVES * (NTW * 16 + 2 * hmax);
+  const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
+                     (size_t)NWAVES * 32 * 4 + tile_rows * RS;
+  if (lds > 160 * 1024 || hmax > MRF_HMAX) return MV_ERR_UNSUPPORTED;
+  const size_t act = mrf_act_bytes(B, Tn, sizeof(T));
+  T* fbuf = reinterpret_cast<T*>(ws);
+  T* xbuf[2] = {reinterpret_cast<T*>(ws + act), reinterpret_cast<T*>(ws + 2 * act)};
+  float* part5 = reinterpret_cast<float*>(ws + 3 * act);
+  float* part8 = part5 + (size_t)B * nwg * 32;
+  const dim3 grid(nwg, B);
+  const T* xi = (const T*)x;                         // x_i: the input of block i
+  for (int i = 0; i < nblocks; ++i) {
+    const bool stdm = mrf_meta_is_std(metas[i]);
+    const char* pk = (const char*)packed[i];
+    if (i == 0) {
+      mrf_chain_pass<T, NWAVES, NTW, 1>(stdm, grid, lds, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr, nullptr, Tn, nwg,
+                                        nit, eps, nullptr, nullptr);
+    } else {
+      T* xn = xbuf[i & 1];                           // pass A: x_i = GN8_{i-1}(f_{i-1}) + x_{i-1}, written once; statistics of v_i
+      mrf_chain_pass<T, NWAVES, NTW, 4>(stdm, grid, lds, stream, xi, xn, pk, metas[i], nullptr, part5, part8, nullptr, Tn, nwg, nit, eps,
+                                        fbuf, (const char*)packed[i - 1]);
+      xi = xn;
+    }
+    // pass B: stages 1-3 once, f_i -> fbuf, statistics of f_i
+    mrf_chain_pass<T, NWAVES, NTW, 5>(stdm, grid, lds, stream, xi, fbuf, pk, metas[i], part5, nullptr, nullptr, part8, Tn, nwg, nit, eps,
+                                      nullptr, nullptr);
+  }
+  if (ab_out) {
+    constexpr size_t WB = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
+    hipLaunchKernelGGL(mrf_affine_kernel, dim3(B), dim3(64), 0, stream, part8,
+                       reinterpret_cast<const float*>((const char*)packed[nblocks - 1] + WB), ab_out, nwg, Tn, eps);
+    *f_last = fbuf;
+    *x_last = xi;
+    return MV_OK;
+  }
+  MrfMeta mf = metas[nblocks - 1];
+  mf.halo = 0;                                       // pass F touches this wave's own rows only
+  mrf_chain_pass<T, NWAVES, NTW, 6>(true, grid, lds, stream, xi, (T*)out, (const char*)packed[nblocks - 1], mf, nullptr, nullptr, part8,
+                                    nullptr, Tn, nwg, nit, eps, fbuf, (const char*)packed[nblocks - 1]);
   return MV_OK;
 }
 
@@ -715,6 +926,74 @@ extern "C" int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed,
       break;
     case MV_BF16: rc = mrf_launch<bf16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
     case MV_F16: rc = mrf_launch<f16, 8, 4>(x, out, packed, meta, (float*)workspace, dropout_mask, mask_scale, B, T_, eps, (hipStream_t)stream); break;
+    default: return MV_ERR_DTYPE;
+  }
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" size_t mv_mrf_chain_workspace_bytes(int B, int T_, int dtype) {
+  const size_t es = dtype == MV_F32 ? 4 : 2;
+  return 3 * mrf_act_bytes(B, T_, es) + (mv_mrf_workspace_bytes(B, T_, dtype) + 255) / 256 * 256 + (size_t)B * 128 * sizeof(float);
+}
+
+// chain + the generator's output projection (Conv1d(64,1,ks,pad ks/2) + activation): the last block's output is formed inside the
+// output conv's staging loop and never stored
+extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* const* packed, const int* dilations, int nblocks,
+                                       void* workspace, const void* conv_packed, float conv_bias, int ks, int act, int B, int T_,
+                                       float eps, int dtype, void* stream) {
+  MV_CHECK_ARG(x && wave && packed && dilations && workspace && conv_packed && nblocks >= 1 && nblocks <= 8 && B > 0 && B <= 65535 && T_ > 0);
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)workspace & 255) == 0 && ks > 0 && (ks & 1));
+  MrfMeta metas[8];
+  for (int i = 0; i < nblocks; ++i) {
+    MV_CHECK_ARG(packed[i] && ((uintptr_t)packed[i] & 15) == 0);
+    if (!mrf_make_meta(dilations + 3 * i, &metas[i])) return MV_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const size_t es = dtype == MV_F32 ? 4 : 2;
+  float* ab = reinterpret_cast<float*>(ws + 3 * mrf_act_bytes(B, T_, es) + (mv_mrf_workspace_bytes(B, T_, dtype) + 255) / 256 * 256);
+  const void* fl = nullptr;
+  const void* xl_ = nullptr;
+  int rc;
+  switch (dtype) {
+    case MV_F32:
+      rc = mrf_chain_launch<float, 8, 1>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_);
+      if (rc == MV_ERR_UNSUPPORTED) rc = mrf_chain_launch<float, 4, 2>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_);
+      break;
+    case MV_BF16: rc = mrf_chain_launch<bf16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
+    case MV_F16: rc = mrf_chain_launch<f16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
+    default: return MV_ERR_DTYPE;
+  }
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  // conv_packed = mv_conv_out_pack_all image: the fp32 [ks][64] weights come first
+  rc = mvi_conv_out_affine(fl, xl_, ab, (const float*)conv_packed, conv_bias, wave, B, T_, MRF_C, ks, ks / 2, act, dtype, st);
+  if (rc != MV_OK) return rc;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* packed, const int* dilations, int nblocks,
+                                   void* workspace, int B, int T_, float eps, int dtype, void* stream) {
+  MV_CHECK_ARG(x && out && packed && dilations && workspace && nblocks >= 1 && nblocks <= 8 && B > 0 && B <= 65535 && T_ > 0);
+  MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)workspace & 255) == 0);
+  MrfMeta metas[8];
+  for (int i = 0; i < nblocks; ++i) {
+    MV_CHECK_ARG(packed[i] && ((uintptr_t)packed[i] & 15) == 0);
+    if (!mrf_make_meta(dilations + 3 * i, &metas[i])) return MV_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  int rc;
+  switch (dtype) {
+    case MV_F32:
+      rc = mrf_chain_launch<float, 8, 1>(x, out, packed, metas, nblocks, ws, B, T_, eps, st);
+      if (rc == MV_ERR_UNSUPPORTED) rc = mrf_chain_launch<float, 4, 2>(x, out, packed, metas, nblocks, ws, B, T_, eps, st);
+      break;
+    case MV_BF16: rc = mrf_chain_launch<bf16, 8, 4>(x, out, packed, metas, nblocks, ws, B, T_, eps, st); break;
+    case MV_F16: rc = mrf_chain_launch<f16, 8, 4>(x, out, packed, metas, nblocks, ws, B, T_, eps, st); break;
     default: return MV_ERR_DTYPE;
   }
   if (rc != MV_OK) return rc;

@@ -173,6 +173,20 @@ int mv_mrf_pack(const mv_mrf_params* params, int param_dtype, const int* dilatio
 int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int* dilations, void* workspace,
                         const uint8_t* dropout_mask, float mask_scale, int B, int T, float eps, int dtype,
                         void* stream);
+/* nblocks consecutive MultiReceptiveFieldBlocks in one call (the generator's `for blk in mrf_blocks: x = blk(x)`, SURVEY.md appendix A
+ * / grc_lora.py:157-163, eval mode).  Same arithmetic as nblocks calls of mv_mrf_block_fwd_cl, restructured: block i writes its
+ * pre-GroupNorm fusion output once, and GroupNorm(8,64) + the residual add of block i are applied by block i+1's first pass while it
+ * loads its input (2 launches and 320 MFMAs per 64-step tile and block instead of 3 and 512).  packed[i] = mv_mrf_pack of block i,
+ * dilations = nblocks x 3 ints, workspace >= mv_mrf_chain_workspace_bytes bytes (256-byte aligned, fully rewritten per call). */
+size_t mv_mrf_chain_workspace_bytes(int B, int T, int dtype);
+int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* packed, const int* dilations, int nblocks, void* workspace,
+                        int B, int T, float eps, int dtype, void* stream);
+/* The chain followed by the generator's output projection + activation (output_proj Conv1d(64,1,ks,pad ks/2),
+ * torch.tanh): wave [B][1][T] in `dtype`.  The last block's GroupNorm + residual is applied while the output conv stages its input,
+ * so that block's output is never stored.  conv_packed = mv_conv_out_pack_all(output_proj.weight); act as in mv_conv_out_act_cl. */
+int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* const* packed, const int* dilations, int nblocks, void* workspace,
+                            const void* conv_packed, float conv_bias, int ks, int act, int B, int T, float eps, int dtype,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused ODConv1d / ODConvTranspose1d, channels-last.   replaces odconv.py:73-108 / :172-205 (attention ->
