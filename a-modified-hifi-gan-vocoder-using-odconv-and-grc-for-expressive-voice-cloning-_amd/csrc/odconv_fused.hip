@@ -125,11 +125,16 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   using V = typename M::V;
   using WL = WLoad<T>;
   constexpr int ES = M::ES;
+  // fp32 storage: the x tiles are PRE-SPLIT into a hi and a lo bf16 plane per row when they are staged (one split per element);
+  // splitting in load_b() cost ~30 VALU instructions per operand read, NB reads per k-step - more than the k-step's MFMAs
+  constexpr bool SPLIT = (ES == 4);
+  constexpr int LES = 2;                                       // operand element size in LDS
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);                 // [S][OD_MAXK] alpha (KB <= OD_MAXK banks used)
   float* bias_l = alds + S * OD_MAXK;                          // [S][4*MW*16] alpha-mixed bias of this workgroup's rows
   char* xl = reinterpret_cast<char*>(bias_l + S * 4 * MW * 16);
-  const int RS = lds_row_stride(p.Cin * ES, ES);
+  const int PLANE = p.Cin * LES;                               // byte offset of the lo plane inside a row (SPLIT)
+  const int RS = lds_row_stride(SPLIT ? 2 * PLANE : p.Cin * ES, LES);
 #ifdef MV_OD_TIMING
   long long tmk[8]; int ntm = 0;
 #endif
@@ -172,14 +177,44 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
   {
     const int cpr = p.Cin * ES / 16;
     const int per = p.nrows * cpr;
-    stage_batched<4, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
-      const int s = i / per, rem = i - s * per;
-      const int r = rem / cpr, ch = rem - r * cpr;
-      const int tin = q0 + p.shift_lo + r;
-      if (b0 + s < p.B && tin >= 0 && tin < p.Tin)
-        src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
-      dst = (s * p.nrows + r) * RS + ch * 16;
-    });
+    if constexpr (SPLIT) {
+      constexpr int UB = 4;
+      for (int i0 = tid; i0 < S * per; i0 += 256 * UB) {
+        f32x4 v[UB];
+        int d[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int i = i0 + u * 256;
+          v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+          d[u] = -1;
+          if (i < S * per) {
+            const int s = i / per, rem = i - s * per;
+            const int r = rem / cpr, ch = rem - r * cpr;
+            const int tin = q0 + p.shift_lo + r;
+            d[u] = (s * p.nrows + r) * RS + ch * 8;
+            if (b0 + s < p.B && tin >= 0 && tin < p.Tin)
+              v[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+          if (d[u] >= 0) {
+            u32x2 hi, lo;
+            Mma<float>::split4(v[u], hi, lo);
+            *reinterpret_cast<u32x2*>(xl + d[u]) = hi;
+            *reinterpret_cast<u32x2*>(xl + d[u] + PLANE) = lo;
+          }
+      }
+    } else {
+      stage_batched<4, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
+        const int s = i / per, rem = i - s * per;
+        const int r = rem / cpr, ch = rem - r * cpr;
+        const int tin = q0 + p.shift_lo + r;
+        if (b0 + s < p.B && tin >= 0 && tin < p.Tin)
+          src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
+        dst = (s * p.nrows + r) * RS + ch * 16;
+      });
+    }
   }
   __syncthreads();
   OD_TM();
@@ -255,14 +290,14 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
     const bool kvalid = (4 * kstep + g) < p.nchunks;
     const int shift = p.transposed ? -tap : (tap * p.dil - p.pad);
     const int rbase = kvalid ? (shift - p.shift_lo + col) : col;
-    const int coff = kvalid ? c8 * 8 * ES : 0;
+    const int coff = kvalid ? c8 * 8 * LES : 0;
     const int bbase = rbase * RS + coff;             // 32-bit LDS offsets
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       // all B fragments of this sample first (independent LDS reads in flight together), then the MFMAs
       V bfr[NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) bfr[n] = M::load_b(xl + (s * p.nrows * RS + bbase + n * 16 * RS));
+      for (int n = 0; n < NB; ++n) bfr[n] = M::load_bp(xl + (s * p.nrows * RS + bbase + n * 16 * RS), PLANE);
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -958,7 +993,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
                      hipStream_t stream, int* slots_out) {
   using M = Mma<T>;
   p.nrows = NB * 16 + (p.ntaps - 1) * (p.transposed ? 1 : p.dil);
-  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(p.Cin * M::ES, M::ES);
+  const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(M::ES == 4 ? 4 * p.Cin : p.Cin * M::ES, 2);
   const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
   const size_t lds = sizeof(float) * (S * OD_MAXK + S * 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
