@@ -176,11 +176,11 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic(kernel_substr, dtype_tag):
-    """HBM bytes per launch group from the committed PMC summary (profiles/*_pmc_traffic.json, tools/profile_summary.py), or None
-    when no summary matches this dtype or the kernel source has changed since it was taken (sha1 recorded in the summary)."""
+def _pmc_summaries(dtype_tag, files=None):
+    """Committed PMC summaries (profiles/*_pmc_traffic.json, tools/profile_summary.py) taken at this dtype from the kernel sources
+    this run is using (sha1 of csrc/* recorded in the summary); newest file name last."""
     pdir = os.path.join(ROOT, "profiles")
-    best = None
+    out = []
     for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
         if not f.endswith("_pmc_traffic.json"):
             continue
@@ -192,16 +192,31 @@ def pmc_traffic(kernel_substr, dtype_tag):
             continue
         ok = True
         for src, sha in j.get("sources", {}).items():
+            if files is not None and src not in files:
+                continue                   # only the sources the quoted kernel is built from have to be unchanged
             path = os.path.join(PKG, "csrc", src)
             ok = ok and os.path.exists(path) and hashlib.sha1(open(path, "rb").read()).hexdigest() == sha
-        if not ok:
-            continue
-        tot = 0
+        if ok:
+            out.append((f, j))
+    return out
+
+
+def pmc_traffic(kernel_substr, dtype_tag, per_launch_of=None, files=None):
+    """HBM bytes from the committed PMC summary, or None when no summary matches this dtype / these kernel sources.
+    Sum over the kernels whose name contains `kernel_substr` of (fetch + write bytes); divided by the launch count of the kernel
+    whose name contains `per_launch_of` (e.g. one MRF block = all mrf_kernel passes / launches of its once-per-block pass),
+    or - without it - the plain per-launch average of the single matching kernel."""
+    best = None
+    for f, j in _pmc_summaries(dtype_tag, files):
+        tot, marker = 0.0, 0
         for name, k in j.get("kernels", {}).items():
             if kernel_substr in name:
-                tot += k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
-        if tot:
-            best = {"bytes": int(tot), "file": "profiles/" + f}
+                per = k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]
+                tot += per * (k["launches"] if per_launch_of else 1)
+            if per_launch_of and kernel_substr in name and per_launch_of in name:
+                marker += k["launches"]
+        if tot and (marker or not per_launch_of):
+            best = {"bytes": int(tot / marker) if per_launch_of else int(tot), "file": "profiles/" + f}
     return best
 
 
@@ -331,22 +346,36 @@ def main():
     from hifigan_modified.fused import generator_fused_for
 
     def mrf_roofline(g, m, s, e, tag):
+        """One MRF block as the generator really runs it: fp32 storage = a third of the three-block chain (mv_mrf_chain_fwd_cl:
+        PASS 1 + 3 x PASS 5 + 2 x PASS 4 + the materialising PASS 6), 16-bit storage = the per-block kernel (3 pass launches)."""
         fzz = generator_fused_for(g)
         with torch.no_grad():
             st_ = g(m, s, e, return_stages=True)
             x_cl = ops.nct_to_ntc(st_["up%d" % (len(g.upsample_layers) - 1)])
-            run = (lambda: fzz.mrfs[0].forward_cl(x_cl)) if fzz is not None else (lambda: g.mrf_blocks[0](st_["up3"]))
-            ms = graph_time_ms(run)
+            nblk, chained = 1, False
+            if fzz is not None and fzz.chain is not None and x_cl.dtype == torch.float32:
+                run, nblk, chained = (lambda: fzz.chain.forward_cl(x_cl)), len(fzz.mrfs), True
+            elif fzz is not None:
+                run = lambda: fzz.mrfs[0].forward_cl(x_cl)
+            else:
+                run = lambda: g.mrf_blocks[0](st_["up3"])
+            ms = graph_time_ms(run) / nblk
         elt = x_cl.element_size()
         alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block, once (SURVEY 8(d): 64 ch in + 64 ch out per sample)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        tr = pmc_traffic("mrf_kernel", tag) if (B == 32 and Tm == 32) else None
-        r = {"bound": "hbm", "kernel": "mv::mrf_kernel<%s> (fused MRF block = 3 pass launches)" % tag, "achieved": round(achieved, 1),
+        # one block = every mrf_kernel pass of this storage type / launches of the pass that runs once per block (chain: 5, else 3)
+        cname = {"fp32": "mrf_kernel<float", "bf16": "mrf_kernel<__hip_bfloat16", "fp16": "mrf_kernel<_Float16"}[tag]
+        tr = pmc_traffic(cname, tag, per_launch_of=(", 5, " if chained else ", 3, "),
+                         files=("mrf_fused.hip", "mfma.h", "common.h")) if (B == 32 and Tm == 32) else None
+        how = ("three-block chain / 3: 7 pass launches per 3 blocks, GroupNorm(8,64) deferred into the next block's load"
+               if chained else "per-block kernel = 3 pass launches")
+        r = {"bound": "hbm", "kernel": "mv::mrf_kernel<%s> (fused MRF block; %s)" % (tag, how), "achieved": round(achieved, 1),
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
              "traffic": tr["bytes"] if tr else None, "traffic_source": tr["file"] if tr else None,
              "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
-             "note": "3 passes read x once each and write once (GroupNorm is global in T): actual HBM bytes = 2x algorithmic; "
-                     "with split operands (fp32 storage) the block issues 3 MFMAs per product and is matrix-pipe / LDS bound"}
+             "note": "GroupNorm is global in T, so a block is several passes over the stream: per-block form 3 reads + 1 write, chain "
+                     "form 5 transfers per block; with split operands (fp32 storage) every product is 3 MFMAs and the block is "
+                     "matrix-pipe / LDS bound, not HBM bound (DESIGN.md section 4)"}
         return r, st_, fzz
 
     roof = od_roof = None
@@ -560,7 +589,10 @@ def main():
             ms = e0.elapsed_time(e1) / 10
             flops = 2.0 * Bd * Hd * Wd * 256 * 128 * 9
             ach = flops / (ms * 1e-3) / 1e12
-            ttr = pmc_traffic("dconv_cl_wide_kernel", "train_" + args.train_dtype)
+            tname = {"bf16": "__hip_bfloat16", "fp16": "_Float16"}[args.train_dtype]
+            # average over every launch of this instantiation in a training step (the 128->256 forward and the data-gradient launches it also serves)
+            ttr = pmc_traffic("dconv_cl_wide_kernel<%s, 2, 4, 8, 64>" % tname, "train_" + args.train_dtype,
+                              files=("disc_fused.hip", "mfma.h", "common.h"))
             train["roofline"] = {"bound": "mfma", "kernel": "mv::dconv_cl_wide_kernel<%s,2,4,8,64> (Conv2d 128->256 3x3 + LeakyReLU, implicit GEMM, 8 waves: 256 rows x 256 positions)" % args.train_dtype,
                                  "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
                                  "traffic": ttr["bytes"] if ttr else None, "flops_per_launch": flops, "ms_per_launch": round(ms, 4)}

@@ -221,6 +221,7 @@ def test_generator_full_from_seed(H, fixture, kw, dtype):
     # fp32 storage (bf16x3 MFMA operands) meets the north_star 1e-3 with a wide margin; fp16/bf16 storage is bounded
     # by rounding-floor x output-conv amplification (DESIGN.md "Precision"): measured 2e-3..7e-3 / 2e-2..7e-2
     bound = {torch.float32: 2e-4, torch.float16: 1e-2, torch.bfloat16: 8e-2}[dtype]
+    print(f"[parity] {fixture} {dtype}: waveform rel-L2 {err:.3e}")
     assert err < bound, f"{fixture} {dtype}: waveform rel-L2 {err:.3e}"
     if dtype == torch.float32:
         for k in ("film", "up0", "up1", "up2", "up3", "mrf0", "mrf1", "mrf2"):
@@ -331,6 +332,8 @@ def test_generator_fused_pipeline_every_stage(H, dtype):
     ew = O.rel_l2(st["wave"].float().cpu(), ref["wave"])
     eg = O.rel_l2(st_g["wave"].float().cpu(), ref["wave"])
     wave_bound = {torch.float32: 2e-4, torch.float16: 1e-2, torch.bfloat16: 6e-2}[dtype]
+    print(f"[parity] fused pipeline B=3 T=13 {dtype}: wave {ew:.3e} (generic {eg:.3e}) worst stage "
+          f"{max(O.rel_l2(st[k].float().cpu(), ref[k]) for k in ('film', 'up0', 'up1', 'up2', 'up3', 'mrf0', 'mrf1', 'mrf2')):.3e}")
     assert ew < wave_bound, f"wave {dtype}: {ew:.2e} (generic path {eg:.2e})"
     # fewer stored roundings: the fused path must not be less accurate than the generic one (with slack for noise)
     assert ew < 1.5 * eg + 1e-5
