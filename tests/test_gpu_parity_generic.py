@@ -1,9 +1,12 @@
 """GPU parity of the HIP path (through the C ABI) against the golden vectors generated from the
 reference and against the CPU oracle.  Tolerances (relative L2):
-  fp32 storage : 1e-4 per module, 2e-4 on whole-generator waveform (summation order only)
-  fp16 storage : 1e-3 on the waveform (north_star tolerance)
-  bf16 storage : 4e-3 per module / waveform - the bf16 rounding floor of this network (each stored
-                 activation costs ~1e-3; measured in DESIGN.md), reported by bench.py
+  fp32 storage (split bf16 MFMA operands) - THE parity-grade mode: north_star's 1e-3 on the waveform is asserted at the full C2
+                 size (test_full_c2_batch_properties, 32 clips) and on both sample rates (generator_full_*); the bounds actually used are
+                 tighter (1e-4 per module, 2e-4 waveform: summation order only)
+  fp16 / bf16 storage - OUT of north_star's tolerance by construction: tools/error_budget.py shows that rounding alone puts any
+                 single-16-bit-operand pipeline at 1.5e-3 / 1.2e-2 (22 kHz; 48 kHz worse) - DESIGN.md section 5.  Their bounds below are
+                 guard rails at about 2x the measured value of each case, so that a kernel regression shows; they are NOT a claim that
+                 these modes meet 1e-3 (bench.py reports them with parity_ok = false)
 MPD fold index map: exact equality."""
 import numpy as np
 import pytest
@@ -218,9 +221,10 @@ def test_generator_full_from_seed(H, fixture, kw, dtype):
     wave = st["wave"]
     assert wave.shape == (1, 1, 8192)
     err = O.rel_l2(wave.float().cpu(), torch.from_numpy(g["wave"]))
-    # fp32 storage (bf16x3 MFMA operands) meets the north_star 1e-3 with a wide margin; fp16/bf16 storage is bounded
-    # by rounding-floor x output-conv amplification (DESIGN.md "Precision"): measured 2e-3..7e-3 / 2e-2..7e-2
-    bound = {torch.float32: 2e-4, torch.float16: 1e-2, torch.bfloat16: 8e-2}[dtype]
+    # fp32 storage (split MFMA operands) meets north_star's 1e-3 with a wide margin (measured 0 / 7.0e-5: the 22 kHz clip of this
+    # fixture is fully saturated).  16-bit storage: guard rails at 2x the measured 48 kHz values (fp16 4.1e-3, bf16 3.4e-2), out of
+    # the 1e-3 tolerance by construction (module docstring)
+    bound = {torch.float32: 2e-4, torch.float16: 8e-3, torch.bfloat16: 6.5e-2}[dtype]
     print(f"[parity] {fixture} {dtype}: waveform rel-L2 {err:.3e}")
     assert err < bound, f"{fixture} {dtype}: waveform rel-L2 {err:.3e}"
     if dtype == torch.float32:
@@ -325,13 +329,14 @@ def test_generator_fused_pipeline_every_stage(H, dtype):
         st = m(mel.cuda().to(dtype), spk.cuda().to(dtype), emo.cuda().to(dtype), return_stages=True)
         st_g = m(mel.cuda().to(dtype), spk.cuda().to(dtype), emo.cuda().to(dtype), return_stages=True, force_generic=True)
     assert st["wave"].shape == (3, 1, 13 * 256)
-    stage_bound = {torch.float32: 5e-5, torch.float16: 2e-3, torch.bfloat16: 1.2e-2}[dtype]
+    # measured: worst stage 1.1e-5 / 8.0e-4 / 6.6e-3, waveform 1.7e-5 / 1.08e-3 / 1.07e-2 (fp32 / fp16 / bf16); 16-bit = 2x guard rails
+    stage_bound = {torch.float32: 5e-5, torch.float16: 1.6e-3, torch.bfloat16: 1.3e-2}[dtype]
     for k in ("film", "up0", "up1", "up2", "up3", "mrf0", "mrf1", "mrf2"):
         e = O.rel_l2(st[k].float().cpu(), ref[k])
         assert e < stage_bound, f"{k} {dtype}: {e:.2e}"
     ew = O.rel_l2(st["wave"].float().cpu(), ref["wave"])
     eg = O.rel_l2(st_g["wave"].float().cpu(), ref["wave"])
-    wave_bound = {torch.float32: 2e-4, torch.float16: 1e-2, torch.bfloat16: 6e-2}[dtype]
+    wave_bound = {torch.float32: 2e-4, torch.float16: 2.2e-3, torch.bfloat16: 2.2e-2}[dtype]
     print(f"[parity] fused pipeline B=3 T=13 {dtype}: wave {ew:.3e} (generic {eg:.3e}) worst stage "
           f"{max(O.rel_l2(st[k].float().cpu(), ref[k]) for k in ('film', 'up0', 'up1', 'up2', 'up3', 'mrf0', 'mrf1', 'mrf2')):.3e}")
     assert ew < wave_bound, f"wave {dtype}: {ew:.2e} (generic path {eg:.2e})"
@@ -416,6 +421,27 @@ def test_full_c2_batch_properties(H):
             assert O.rel_l2(wave[i:i + 1].cpu(), solo.cpu()) < 1e-4, i
             ref = O.generator_forward(mel[i:i + 1], sd, "", spk[i:i + 1], emo[i:i + 1])
             assert O.rel_l2(wave[i:i + 1].cpu(), ref) < 1e-3, i
+
+
+def test_full_c5_48k_batch_meets_north_star(H):
+    """BASELINE configs[4]'s per-GPU share at its full size (128-mel, upsample [8,8,4,2], B=32 x 16 frames -> 8192 samples) in the
+    parity-grade mode: two of the 32 clips against the oracle within north_star's 1e-3 (measured ~7e-5; this configuration saturates
+    tanh less than the 22 kHz one, so it is the harder parity case - fp16 storage sits at 5e-3 here), per-sample independence."""
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator(mel_channels=128, upsample_factors=[8, 8, 4, 2])
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.cuda().train(False)
+    torch.manual_seed(1)
+    mel, spk, emo = torch.randn(32, 128, 16), torch.randn(32, 192), torch.randn(32, 384)
+    with torch.no_grad():
+        wave = gen(mel.cuda(), spk.cuda(), emo.cuda())
+        assert wave.shape == (32, 1, 8192) and wave.dtype == torch.float32
+        for i in (3, 30):
+            ref = O.generator_forward(mel[i:i + 1], sd, "", spk[i:i + 1], emo[i:i + 1], upsample_factors=(8, 8, 4, 2))
+            e = O.rel_l2(wave[i:i + 1].cpu(), ref)
+            assert e < 1e-3, (i, e)
+            solo = gen(mel[i:i + 1].cuda(), spk[i:i + 1].cuda(), emo[i:i + 1].cuda())
+            assert O.rel_l2(wave[i:i + 1].cpu(), solo.cpu()) < 1e-4, i
 
 
 @pytest.mark.parametrize("kind,arg", [("2d", 2), ("2d", 11), ("1d", 1)])
