@@ -114,6 +114,78 @@ __device__ long long* od_dbg = nullptr;
 #else
 #define OD_TM() do {} while (0)
 #endif
+// ------------------------------------------------------------------------------------------------ attention prologue
+// alpha[s][:] = softmax_k( Wa . mean_t x + ba ) (odconv.py:36-40,85) for the S samples of a workgroup, from the PRODUCER's partial
+// channel sums (pooled_in: pool_n = slots x rows floats per sample, row % Cin = channel).  All 256 threads take part: thread t owns
+// channel t % Cin and every G-th partial of it (G = 256 / Cin thread groups), all its loads are independent and issued together;
+// the G group sums and then the K logits are added in a fixed order, so the result does not depend on timing (no atomics).
+// (One wave per (sample, bank) walking pool_n elements with a dependent load per step cost 7-12 us per layer: a chain of
+// pool_n / 64 L2 round trips in front of everything else.)  `scratch` = >= S * 256 floats of LDS that nothing else uses yet.
+template <typename T>
+__device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scratch, int S, int b0, const OdP& p,
+                                                       const float* __restrict__ pooled_in, const T* __restrict__ att_w,
+                                                       const T* __restrict__ att_b) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int Cin = p.Cin;
+  const int npc = p.pool_n / Cin;                       // partials per channel
+  if (Cin <= 256) {
+    const int G = 256 / Cin, c = tid % Cin, gq = tid / Cin;          // Cin is a multiple of 8; threads beyond G * Cin idle
+    for (int s = 0; s < S; ++s) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (gq < G && b0 + s < p.B) {
+        const float* src = pooled_in + (long)(b0 + s) * p.pool_n + c;
+        int j = gq;
+        for (; j + 3 * G < npc; j += 4 * G) {
+          a0 += src[(long)j * Cin]; a1 += src[(long)(j + G) * Cin]; a2 += src[(long)(j + 2 * G) * Cin]; a3 += src[(long)(j + 3 * G) * Cin];
+        }
+        for (; j < npc; j += G) a0 += src[(long)j * Cin];
+      }
+      if (gq < G) scratch[(s * G + gq) * Cin + c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int i = tid; i < S * Cin; i += 256) {            // fixed-order sum over the G groups -> scratch[s][0][c]
+      const int s = i / Cin, cc = i - s * Cin;
+      float a = 0.f;
+      for (int q = 0; q < G; ++q) a += scratch[(s * G + q) * Cin + cc];
+      scratch[(s * G) * Cin + cc] = a;
+    }
+    __syncthreads();
+    for (int pr = wid; pr < S * p.K; pr += 4) {           // logits: wave per (sample, bank)
+      const int s = pr / p.K, kb = pr % p.K;
+      float acc = 0.f;
+      for (int cc = lane; cc < Cin; cc += 64) acc += ld<T>(att_w + (long)kb * Cin + cc) * scratch[(s * G) * Cin + cc];
+      acc = wave_sum(acc);
+      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+    }
+  } else {
+    // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel; a thread owns channels tid, tid + 256, ...
+    for (int s = 0; s < S; ++s)
+      for (int c = tid; c < Cin; c += 256) {
+        float a = 0.f;
+        if (b0 + s < p.B) {
+          const float* src = pooled_in + (long)(b0 + s) * p.pool_n + c;
+          for (int j = 0; j < npc; ++j) a += src[(long)j * Cin];
+        }
+        scratch[s * Cin + c] = a;                        // needs S * Cin floats of scratch
+      }
+    __syncthreads();
+    for (int pr = wid; pr < S * p.K; pr += 4) {
+      const int s = pr / p.K, kb = pr % p.K;
+      float acc = 0.f;
+      for (int cc = lane; cc < Cin; cc += 64) acc += ld<T>(att_w + (long)kb * Cin + cc) * scratch[s * Cin + cc];
+      acc = wave_sum(acc);
+      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+    }
+  }
+  __syncthreads();
+  if (tid < S) {
+    float m = -INFINITY, den = 0.f;
+    for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
+    for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
+    for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int S, int MW, int NB, bool PF, int KB>
 __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
@@ -154,23 +226,8 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
       alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
     }
   } else {
-    // wave w computes logits of (s,kb) pairs w, w+4, ...
-    for (int pr = wid; pr < S * p.K; pr += 4) {
-      const int s = pr / p.K, kb = pr % p.K;
-      float acc = 0.f;
-      if (b0 + s < p.B)
-        for (int i = lane; i < p.pool_n; i += 64)    // fixed summation order over the producer's partial sums: deterministic
-          acc += ld<T>(att_w + (long)kb * p.Cin + i % p.Cin) * pooled_in[(long)(b0 + s) * p.pool_n + i];
-      acc = wave_sum(acc);
-      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
-    }
-    __syncthreads();
-    if (tid < S) {
-      float m = -INFINITY, den = 0.f;
-      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
-      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
-      for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
-    }
+    od_alpha_from_partials<T>(alds, reinterpret_cast<float*>(xl), S, b0, p, pooled_in, att_w, att_b);   // xl: not staged yet
+    __syncthreads();                                   // the scratch is dead before the x tiles land in it
   }
   OD_TM();
   // ---- stage x tiles: input rows q0+shift_lo .. +nrows-1 of every sample, zero outside [0,Tin)
@@ -454,19 +511,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
   if (alpha_in) {
     if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
   } else {
-    for (int kb = wid; kb < p.K; kb += 4) {
-      float a = 0.f;
-      for (int i = lane; i < p.pool_n; i += 64) a += ld<T>(att_w + (long)kb * CIN + i % CIN) * pooled_in[(long)b * p.pool_n + i];
-      a = wave_sum(a);
-      if (lane == 0) alds[kb] = a / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      float m = -INFINITY, den = 0.f;
-      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[kb]);
-      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[kb] - m);
-      for (int kb = 0; kb < p.K; ++kb) alds[kb] = expf(alds[kb] - m) / den;
-    }
+    od_alpha_from_partials<T>(alds, reinterpret_cast<float*>(xl), 1, b, p, pooled_in, att_w, att_b);   // xl: nothing committed yet
   }
   // x tile prefetch registers: piece i = tid + 256 j of the [NROWS][CPR] tile
   uint4 xreg[XP];
@@ -704,6 +749,10 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   const int b0 = blockIdx.y * S;
   const int n_mt = p.M / 16;
   const int ZR = p.nrows - 1;                      // index of the all-zero row
+#ifdef MV_OD_TIMING
+  long long tmk[8]; int ntm = 0;
+#endif
+  OD_TM();
 
   // ---- alpha (odconv.py:36-40)
   if (alpha_in) {
@@ -712,23 +761,10 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
       alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
     }
   } else {
-    for (int pr = wid; pr < S * p.K; pr += 4) {
-      const int s = pr / p.K, kb = pr % p.K;
-      float acc = 0.f;
-      if (b0 + s < p.B)
-        for (int i = lane; i < p.pool_n; i += 64)    // fixed summation order over the producer's partial sums: deterministic
-          acc += ld<T>(att_w + (long)kb * p.Cin + i % p.Cin) * pooled_in[(long)(b0 + s) * p.pool_n + i];
-      acc = wave_sum(acc);
-      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
-    }
-    __syncthreads();
-    if (tid < S) {
-      float m = -INFINITY, den = 0.f;
-      for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
-      for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
-      for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
-    }
+    od_alpha_from_partials<T>(alds, reinterpret_cast<float*>(xl), S, b0, p, pooled_in, att_w, att_b);   // xl: not staged yet
+    __syncthreads();                                   // the scratch is dead before the x tiles land in it
   }
+  OD_TM();
   // ---- stage the whole (short) input of every sample: row r <-> input step r + shift_lo, last row = zeros
   {
     const int cpr = p.Cin * ES / 16;               // 16-byte global pieces per row
@@ -773,6 +809,7 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
     }
   }
   __syncthreads();
+  OD_TM();
 
   // out = sum_kb alpha[b,kb] * D_kb; D_kb lives in `acc` while bank kb streams and is folded into `out` at the end of the bank
   f32x4 acc[MW][S][NB], out[MW][S][NB];
@@ -874,6 +911,7 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
     }
   }
 
+  OD_TM();
   // ---- epilogue: bias, activation -> LDS tile [s][q][rows of this workgroup] -> whole-row stores
   __syncthreads();
   constexpr int RW = 64 * MW;
@@ -957,6 +995,13 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
         *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
       }
   }
+#ifdef MV_OD_TIMING
+  OD_TM();
+  if (tid == 0 && od_dbg) {
+    const long wgid = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wgid < 8192) for (int i = 0; i < 8; ++i) od_dbg[wgid * 8 + i] = i < ntm ? tmk[i] - tmk[0] : -1;
+  }
+#endif
 }
 
 template <typename T, int S, int NB, int MW>
@@ -982,8 +1027,27 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
   dim3 grid(cdiv(p.M / 16, 4 * MW), cdiv(p.B, S));
   if (grid.y > 65535) return MV_ERR_UNSUPPORTED;
   if (slots_out) { *slots_out = 1; return MV_OK; }
+#ifdef MV_OD_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 8192 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(od_dbg), &dbg, sizeof(dbg)); }
+  hipMemsetAsync(dbg, 0xff, 8192 * 8 * 8, stream);
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
                      (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p);
+#ifdef MV_OD_TIMING
+  if (++calls == 20) {
+    hipStreamSynchronize(stream);
+    static long long hbuf[8192 * 8];
+    hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+    const long nwg = (long)grid.x * grid.y < 8192 ? (long)grid.x * grid.y : 8192;
+    double avg[8] = {0}; int cnt[8] = {0};
+    for (long w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) { long long v = hbuf[w * 8 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
+    fprintf(stderr, "[kloop timing] S %d MW %d grid %u x %u marks (start, alpha, -, staged, loop, end):", S, MW, grid.x, grid.y);
+    for (int i = 0; i < 8; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
   return MV_OK;
 }
 

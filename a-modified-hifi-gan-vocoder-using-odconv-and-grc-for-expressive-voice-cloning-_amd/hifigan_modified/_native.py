@@ -11,7 +11,7 @@ import re
 from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_DIR, "libmi355x_vocoder.so")
+LIB_PATH = os.environ.get("MV_LIB") or os.path.join(_PKG_DIR, "libmi355x_vocoder.so")   # MV_LIB: a debug build (e.g. -DMV_OD_TIMING)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "mi355x_vocoder.h")
 
 MV_F32, MV_BF16, MV_F16 = 0, 1, 2
