@@ -714,7 +714,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 static inline void mrf_geometry(int B, int Tn, int tile_t, int* nwg, int* nit) {
   const int ntiles = cdiv(Tn, tile_t);
   int it = 1;
-  while (it < 4 && (long)B * cdiv(ntiles, it) > 256 && cdiv(ntiles, it * 2) >= 1 && ntiles >= it * 2) it *= 2;
+  // up to 8 tiles per workgroup: the prologue (48-96 KB of packed weights into LDS) is paid once per workgroup, and at fp32's 128-step
+  // workgroup tiles the C2 batch is 2048 tiles - 512 workgroups of 4 tiles staged the weights twice per CU and pass
+  while (it < 8 && (long)B * cdiv(ntiles, it) > 256 && cdiv(ntiles, it * 2) >= 1 && ntiles >= it * 2) it *= 2;
   *nit = it;
   *nwg = cdiv(ntiles, it);
 }
