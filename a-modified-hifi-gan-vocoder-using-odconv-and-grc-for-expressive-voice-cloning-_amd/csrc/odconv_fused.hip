@@ -497,14 +497,17 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
   using M = Mma<T>;
   using V = typename M::V;
   using WL = WLoad<T>;
-  constexpr int ES = 2, NTAPS = 2, CPR = CIN * ES / 16, CPC = CIN / 8, KST = NTAPS * CIN / 32;
+  // fp32 storage: x tiles PRE-SPLIT into hi / lo bf16 planes at commit (split operands, mfma.h); ES = element size in HBM, LES in LDS
+  constexpr int ES = M::ES, LES = 2, NTAPS = 2, CPR = CIN * ES / 16, CPC = CIN / 8, KST = NTAPS * CIN / 32;
+  constexpr bool SPLIT = (ES == 4);
+  constexpr int PLANE = CIN * LES;
   constexpr int NROWS = NB * 16 + NTAPS - 1, PER = NROWS * CPR, XP = (PER + 255) / 256;
   constexpr int RW = 4 * MW * 16, ORS = RW * ES + 16;
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);                 // [OD_MAXK]
   float* bias_l = alds + OD_MAXK;                              // [RW]
   char* xl = reinterpret_cast<char*>(bias_l + RW);
-  const int RS = lds_row_stride(CIN * ES, ES);
+  const int RS = lds_row_stride(SPLIT ? 2 * PLANE : CIN * ES, LES);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, col = lane & 15, g = lane >> 4;
   const int mt0 = (blockIdx.y * 4 + wid) * MW, b = blockIdx.z, n_mt = p.M / 16, R0 = blockIdx.y * RW;
 
@@ -531,7 +534,15 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
       const int i = tid + j * 256;
       if (i < PER) {
         const int r = i / CPR, ch = i % CPR, tin = q0 + p.shift_lo + r;
-        *reinterpret_cast<uint4*>(xl + r * RS + ch * 16) = (tin >= 0 && tin < p.Tin) ? xreg[j] : make_uint4(0, 0, 0, 0);
+        const uint4 v = (tin >= 0 && tin < p.Tin) ? xreg[j] : make_uint4(0, 0, 0, 0);
+        if constexpr (SPLIT) {
+          u32x2 hi, lo;
+          Mma<float>::split4(__builtin_bit_cast(f32x4, v), hi, lo);
+          *reinterpret_cast<u32x2*>(xl + r * RS + ch * 8) = hi;
+          *reinterpret_cast<u32x2*>(xl + r * RS + PLANE + ch * 8) = lo;
+        } else {
+          *reinterpret_cast<uint4*>(xl + r * RS + ch * 16) = v;
+        }
       }
     }
   };
@@ -599,10 +610,10 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks) {
       const int chunk = 4 * ks + g, tap = chunk / CPC, c8 = chunk % CPC;
-      const int bbase = (-tap - p.shift_lo + col) * RS + c8 * 8 * ES;
+      const int bbase = (-tap - p.shift_lo + col) * RS + c8 * 8 * LES;
       V bfr[NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) bfr[n] = M::load_b(xl + bbase + n * 16 * RS);
+      for (int n = 0; n < NB; ++n) bfr[n] = M::load_bp(xl + bbase + n * 16 * RS, PLANE);
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -668,9 +679,9 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
 template <typename T, int MW, int NB, int CIN>
 static int od_mt_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
                         const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream, int* slots_out) {
-  constexpr int ES = 2;
+  constexpr int ES = Mma<T>::ES;
   const int nrows = NB * 16 + 1;
-  const size_t xbytes = (size_t)nrows * lds_row_stride(CIN * ES, ES);
+  const size_t xbytes = (size_t)nrows * lds_row_stride(ES == 4 ? 4 * CIN : CIN * ES, 2);
   const size_t obytes = (size_t)NB * 16 * (4 * MW * 16 * ES + 16);
   const size_t lds = sizeof(float) * (OD_MAXK + 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 80 * 1024) return MV_ERR_UNSUPPORTED;
@@ -1200,27 +1211,34 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else if (wbytes > (1 << 20)) {         // big kernels, medium sequences: 144-column blocks amortise the aggregation
       rc = MV_ERR_UNSUPPORTED;
-      if constexpr (sizeof(T) == 2) {
+      {
         static int mt1 = -1;
         if (mt1 < 0) { const char* e = getenv("MV_OD_MT1"); mt1 = e ? atoi(e) : 1; }
         // 256 input channels, ks = 2*stride (ups1): 64-row workgroups keep their 16 mixed fragments per wave resident and walk
         // the sample's 96-column tiles - the bank fragments are fetched from L2 and mixed once per (sample, row block) instead
         // of once per tile (37 -> 28.5 us; 144-column tiles without the x look-ahead measured 34 us)
-        if (mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256)
-          rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        if (mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256) {
+          // (fp32: 16 resident fragment PAIRS per wave need 256 VGPRs = one wave per SIMD: 98 us vs 77 on the one-tile kernel - not used)
+          if constexpr (sizeof(T) == 2) rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        }
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 9);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else {                                 // small kernels, long sequences: HBM-streaming regime
       rc = MV_ERR_UNSUPPORTED;
-      if constexpr (sizeof(T) == 2) {
+      {
         static int mt_on = -1;
         if (mt_on < 0) { const char* e = getenv("MV_OD_MT"); mt_on = e ? atoi(e) : 1; }
         if (mt_on && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && (Cin == 64 || Cin == 128)) {
           // 128-column tiles for 64 input channels; 64-column tiles for 128 (8 resident A fragments per M-tile: the wider tile
           // would need > 256 VGPRs, i.e. one wave per SIMD - measured 42 vs 24.5 us)
-          if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
-          else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+          if constexpr (sizeof(T) == 2) {
+            if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+            else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+          } else {   // fp32 (operands are hi/lo register pairs): 64-column tiles; at 128 channels ONE M-tile per wave (two cost a wave per SIMD: 60 us)
+            if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+            else rc = od_mt_launch<T, 1, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);   // ups2 49 -> 38 us
+          }
         }
       }
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 8);
