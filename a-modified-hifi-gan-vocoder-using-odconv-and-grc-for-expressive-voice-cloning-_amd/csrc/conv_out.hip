@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_out_affine_kernel(const T* __restric
   float ra[EPC], rb[EPC];
 #pragma unroll
   for (int j = 0; j < EPC; ++j) { ra[j] = ab[(size_t)b * 2 * C + ch * EPC + j]; rb[j] = ab[(size_t)b * 2 * C + C + ch * EPC + j]; }
-  constexpr int UB = 6;
+  constexpr int UB = 9;      // (256 + ks - 1) rows / 16 row groups = 17 rows per thread: two batches of loads in flight
   for (int r0 = tid / CPR; r0 < rows; r0 += (256 / CPR) * UB) {
     alignas(16) T xv[UB][EPC];
     alignas(16) T fv[UB][EPC];

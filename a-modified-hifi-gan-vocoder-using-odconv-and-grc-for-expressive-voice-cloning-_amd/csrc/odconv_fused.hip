@@ -1199,7 +1199,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
         static int kmw = -1;
         if (kmw < 0) { const char* e = getenv("MV_KLOOP_MW"); kmw = e ? atoi(e) : 0; }
         const int mw_sel = kmw ? kmw : (dtype == MV_F32 ? 2 : 1);
-        if (mw_sel == 2) {
+        if (mw_sel == 2) {   // (four samples per workgroup halve the L2 stream but leave one wave per SIMD: 58.6 us)
           rc = od_kloop_launch<T, 2, 3, 2>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
           if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3, 2>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
         } else {
@@ -1222,7 +1222,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
           if constexpr (sizeof(T) == 2) rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
         }
       }
-      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 9);
+      if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 9);      // (fp32: 64- / 96-column tiles measured 96 / 94 us vs 76)
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else {                                 // small kernels, long sequences: HBM-streaming regime
       rc = MV_ERR_UNSUPPORTED;
