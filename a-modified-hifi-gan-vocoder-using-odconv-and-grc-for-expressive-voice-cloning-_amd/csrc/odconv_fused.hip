@@ -1072,7 +1072,7 @@ static int od_launch(const void* x, const void* wp, const void* bias, const floa
   const size_t obytes = (size_t)S * NB * 16 * (4 * MW * 16 * M::ES + 16);    // staged output tile reuses the x region
   const size_t lds = sizeof(float) * (S * OD_MAXK + S * 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = odconv_cl_kernel<T, S, MW, NB, (PFW && M::ES == 2), KB>;
+  auto kern = odconv_cl_kernel<T, S, MW, NB, (PFW && (M::ES == 2 || MW * NB <= 3)), KB>;   // fp32: prefetch only in the small (input_proj) instantiation
   static size_t lds_set = 0;
   if (lds > lds_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
