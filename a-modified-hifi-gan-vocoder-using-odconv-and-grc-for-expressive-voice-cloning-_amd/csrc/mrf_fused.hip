@@ -468,6 +468,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
       for (int sidx = 0; sidx < 14; ++sidx) {
         if (sidx + 1 < 14) ld_step(sidx + 1, (sidx + 1) & 1);
+        // keep the NEXT step's operand reads above this step's MFMAs: left alone, the scheduler sinks every ds_read to just in
+        // front of its first use (r, s_waitcnt lgkmcnt(0), MFMA, r, wait, MFMA ... in the ISA) and each MFMA pays an LDS round trip
+        __builtin_amdgcn_sched_barrier(0);
         const int tap = sidx >> 1, set = sidx & 1;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
             for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(afr[set][m], bfr[set][n], v[m][n]);
           }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else
     for (int tap = 0; tap < meta.ntaps; ++tap) {
@@ -759,7 +763,7 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
   hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
                      part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
 #ifdef MV_MRF_TIMING
-  if (++calls == 40) {
+  if (++calls == 20) {
     hipStreamSynchronize(stream);
     static long long hbuf[3 * 65536 * 12];
     hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
