@@ -607,17 +607,31 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
     for (int mw = 0; mw < MW; ++mw)
 #pragma unroll
       for (int n = 0; n < NB; ++n) acc[mw][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KST; ++ks) {
+    // operand double buffer: the B fragments of k-step ks+1 are read from LDS while the MFMAs of k-step ks run; the scheduling
+    // barriers keep it that way (the scheduler otherwise sinks each read to just in front of its MFMA: r r wait M M r r wait ...)
+    // (not at 256 input channels: with 16 resident A fragments the second operand set costs the second wave per SIMD - 30 -> 40 us)
+    constexpr bool DBUF = (CIN <= 128);
+    V bfr[DBUF ? 2 : 1][NB];
+    auto ldb = [&](int ks, int set) {
       const int chunk = 4 * ks + g, tap = chunk / CPC, c8 = chunk % CPC;
       const int bbase = (-tap - p.shift_lo + col) * RS + c8 * 8 * LES;
-      V bfr[NB];
 #pragma unroll
-      for (int n = 0; n < NB; ++n) bfr[n] = M::load_bp(xl + bbase + n * 16 * RS, PLANE);
+      for (int n = 0; n < NB; ++n) bfr[set][n] = M::load_bp(xl + bbase + n * 16 * RS, PLANE);
+    };
+    if constexpr (DBUF) ldb(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+      if constexpr (DBUF) {
+        if (ks + 1 < KST) ldb(ks + 1, (ks + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        ldb(ks, 0);
+      }
 #pragma unroll
       for (int n = 0; n < NB; ++n)
 #pragma unroll
-        for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(afr[mw][ks], bfr[n], acc[mw][n]);
+        for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(afr[mw][ks], bfr[DBUF ? (ks & 1) : 0][n], acc[mw][n]);
+      if constexpr (DBUF) __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                           // x tile consumed: reuse the region as the output tile
     char* ol = xl;
