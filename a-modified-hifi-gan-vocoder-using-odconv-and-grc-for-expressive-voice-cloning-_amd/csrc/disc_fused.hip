@@ -298,6 +298,9 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
         V bf[NB];
 #pragma unroll
         for (int n = 0; n < NB; ++n) bf[n] = M::load_b(brow + j * 32 * ES + (long)(n * 16) * RS);
+        // all NB operand reads in flight before the first MFMA: left alone, the scheduler issues them two at a time, each pair
+        // right in front of the 2 x MW MFMAs that use it (rr wait MMMM wait MMMM rr ...), one LDS round trip per 8 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
