@@ -85,99 +85,193 @@ __global__ __launch_bounds__(64) void odconv_attn_pooled_kernel(const float* __r
   }
 }
 
-// ---------------------------------------------------------------- generator prologue (one launch, one workgroup per sample)
+// ---------------------------------------------------------------- generator prologue (one launch)
 // Everything the channels-last generator needs before its first conv, fused: (1) input_proj's ODConv attention
 // alpha = softmax(Wa . mean_t mel + ba) (odconv.py:36-40), (2) mel [C][T] -> channels-last [T][C], (3) the FiLM projection
 // proj = W . cond + b with cond = cat(spk, emo) truncated / zero-padded to the projection's input width (grc_lora.py:82-105),
-// (4) zeroing of this sample's share of the pooled-sum buffers the upsamplers accumulate into.
+// (4) zeroing of the buffers the caller names (none since the pooling sums became per-workgroup partials).
+// Two workgroup roles in one grid.  Workgroups [0, B): one sample each - (1), (2), (4).  Workgroups [B, B + n_film): one
+// (row group, sample group) of the FiLM projection each - PRO_SG samples x one row per wave, so the projection weights cross
+// L2 -> CU once per sample GROUP.  (With the projection inside the per-sample workgroups every one of them pulled the whole
+// weight matrix - 229 KB in fp32 - through its CU's 64 B/clk vector-memory path: 5 of the kernel's 13 us; the attention part was
+// another 7 us of wave-tree reductions, 64-way LDS bank conflicts of the [C][T] tile read column-wise, and barriers.)
+constexpr int PRO_SG = 8;      // samples per FiLM workgroup
+constexpr int PRO_FI = 8;      // projection inputs per lane held in registers (cond_dim <= 64 * PRO_FI on the fast path)
+#ifdef MV_PRO_TIMING
+__device__ long long* pro_dbg = nullptr;
+#define PRO_TM() do { if (ntm < 8) tmk[ntm++] = clock64(); } while (0)
+#else
+#define PRO_TM() do {} while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(1024) void gen_prologue_kernel(const T* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
                                                            const T* __restrict__ spk, const T* __restrict__ emo, const T* __restrict__ film_w,
                                                            const T* __restrict__ film_b, float* __restrict__ alpha, T* __restrict__ x_cl,
-                                                           T* __restrict__ film_proj, float* __restrict__ zero_buf, long zero_n, int C,
-                                                           int Tn, int K, int ds, int de, int cond_dim, int F2) {
-  extern __shared__ float sm[];          // [C*Tn] the sample, [C] means, [K] logits, [cond_dim] condition
-  float* xs = sm;
-  float* mean = xs + C * Tn;
-  float* logit = mean + C;
-  float* cond = logit + K;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x, nw = nt >> 6;
-  const T* xb = mel + (long)b * C * Tn;
-  for (int i = tid; i < C * Tn; i += nt) xs[i] = ld<T>(xb + i);
-  for (int i = tid; i < cond_dim; i += nt) {
-    float v = 0.f;
-    if (i < ds) v = ld<T>(spk + (long)b * ds + i);
-    else if (i < ds + de) v = ld<T>(emo + (long)b * de + (i - ds));
-    cond[i] = v;
+                                                           T* __restrict__ film_proj, float* __restrict__ zero_buf, long zero_n, int B,
+                                                           int C, int Tn, int K, int ds, int de, int cond_dim, int F2) {
+  extern __shared__ float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nt = blockDim.x, nw = nt >> 6;
+#ifdef MV_PRO_TIMING
+  long long tmk[8]; int ntm = 0;
+#endif
+  PRO_TM();
+
+  if ((int)blockIdx.x >= B) {
+    // ---- FiLM role: rows j = rg * nw + wid, samples s0 .. s0 + PRO_SG
+    const int fw = blockIdx.x - B, n_rg = (F2 + nw - 1) / nw;
+    const int rg = fw % n_rg, s0 = (fw / n_rg) * PRO_SG;
+    const int j = rg * nw + wid;
+    float* cl = sm;                                              // [PRO_SG][cond_dim] the condition vectors
+    const bool fast = cond_dim <= 64 * PRO_FI;
+    float wv[PRO_FI];
+    if (fast) {
+#pragma unroll
+      for (int i = 0; i < PRO_FI; ++i)
+        wv[i] = (j < F2 && lane + 64 * i < cond_dim) ? ld<T>(film_w + (long)j * cond_dim + lane + 64 * i) : 0.f;
+    }
+    const float bj = (film_b && j < F2) ? ld<T>(film_b + j) : 0.f;
+    for (int e = tid; e < PRO_SG * cond_dim; e += nt) {          // cat(spk, emo), truncated / zero-padded (grc_lora.py:82-105)
+      const int s = e / cond_dim, i = e - s * cond_dim, b = s0 + s;
+      float v = 0.f;
+      if (b < B) {
+        if (i < ds) v = ld<T>(spk + (long)b * ds + i);
+        else if (i < ds + de) v = ld<T>(emo + (long)b * de + (i - ds));
+      }
+      cl[e] = v;
+    }
+    __syncthreads();
+    float a[PRO_SG];
+    if (fast) {
+#pragma unroll
+      for (int s = 0; s < PRO_SG; ++s) {
+        a[s] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PRO_FI; ++i) if (lane + 64 * i < cond_dim) a[s] += wv[i] * cl[s * cond_dim + lane + 64 * i];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < PRO_SG; ++s) a[s] = 0.f;
+      if (j < F2)
+        for (int i = lane; i < cond_dim; i += 64) {
+          const float w = ld<T>(film_w + (long)j * cond_dim + i);
+#pragma unroll
+          for (int s = 0; s < PRO_SG; ++s) a[s] += w * cl[s * cond_dim + i];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PRO_SG; ++s) a[s] = wave_sum(a[s]);      // PRO_SG independent trees: their shuffles overlap
+    if (j < F2 && lane < PRO_SG && s0 + lane < B) {
+      float v = a[0];
+#pragma unroll
+      for (int s = 1; s < PRO_SG; ++s) v = lane == s ? a[s] : v;
+      st<T>(film_proj + (long)(s0 + lane) * F2 + j, v + bj);
+    }
+    return;
   }
-  // this sample's slice of the buffers that must be zero before the upsamplers run
+
+  // ---- sample role
+  const int b = blockIdx.x;
+  const int TP = Tn | 1;                 // odd row stride: the [C][T] tile is read row-wise AND column-wise without bank conflicts
+  const int P = nt / C;                  // time slices of the mean (>= 1: the host checks C <= blockDim)
+  float* xs = sm;                        // [C][TP]
+  float* psum = xs + C * TP;             // [P][C] slice sums
+  float* mean = psum + P * C;            // [C]
+  const T* xb = mel + (long)b * C * Tn;
+  // every global load is issued before the first barrier: the mel and (wave 0) the attention weights, into registers
+  if (C * Tn <= 4 * nt) {
+    float mv4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mv4[u] = tid + u * nt < C * Tn ? ld<T>(xb + tid + u * nt) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * nt, c = i / Tn;
+      if (i < C * Tn) xs[c * TP + (i - c * Tn)] = mv4[u];
+    }
+  } else {
+    for (int i = tid; i < C * Tn; i += nt) { const int c = i / Tn; xs[c * TP + (i - c * Tn)] = ld<T>(xb + i); }
+  }
+  constexpr int AK = 4, AWN = 4;         // attention weights wave 0 keeps: banks < AK, channels lane + 64 i, i < AWN
+  const bool areg = K <= AK && C <= 64 * AWN;
+  float aw[AK][AWN], ab[AK];
+  if (wid == 0 && areg) {
+#pragma unroll
+    for (int k = 0; k < AK; ++k) {
+#pragma unroll
+      for (int i = 0; i < AWN; ++i) aw[k][i] = (k < K && lane + 64 * i < C) ? ld<T>(att_w + (long)k * C + lane + 64 * i) : 0.f;
+      ab[k] = (k < K && att_b) ? ld<T>(att_b + k) : 0.f;
+    }
+  }
   {
-    const long per = (zero_n + gridDim.x - 1) / gridDim.x, z0 = (long)b * per;
+    const long per = (zero_n + B - 1) / B, z0 = (long)b * per;
     const long z1 = z0 + per < zero_n ? z0 + per : zero_n;
     for (long i = z0 + tid; i < z1; i += nt) zero_buf[i] = 0.f;
   }
+  PRO_TM();
   __syncthreads();
+  PRO_TM();
   // channels-last copy
   T* yb = x_cl + (long)b * Tn * C;
   for (int i = tid; i < C * Tn; i += nt) {
     const int t = i / C, c = i - t * C;
-    st<T>(yb + i, xs[c * Tn + t]);
+    st<T>(yb + i, xs[c * TP + t]);
   }
-  // attention
-  const float inv = 1.f / (float)Tn;
-  for (int c = wid; c < C; c += nw) {
+  // mean over T (odconv.py:36): P time slices per channel, then the P slice sums in a fixed order
+  if (tid < P * C) {
+    const int part = tid / C, c = tid - part * C;
     float a = 0.f;
-    for (int t = lane; t < Tn; t += 64) a += xs[c * Tn + t];
-    a = wave_sum(a);
-    if (lane == 0) mean[c] = a * inv;
+    for (int t = part; t < Tn; t += P) a += xs[c * TP + t];
+    psum[tid] = a;
   }
-  // FiLM projection: a wave owns 4 output rows at a time (their loads are independent and in flight together); 16-bit
-  // weights are read 16 bytes per lane
-  if (film_proj) {
-    constexpr int EPV = 16 / sizeof(T);
-    const bool vec = sizeof(T) == 2 && cond_dim % EPV == 0 && ((uintptr_t)film_w & 15) == 0;
-    for (int j0 = wid * 4; j0 < F2; j0 += 4 * nw) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      if (vec) {
-        for (int pc = lane; pc < cond_dim / EPV; pc += 64) {
-          uint4 wv[4];
+  PRO_TM();
+  __syncthreads();
+  if (tid < C) {
+    float a = 0.f;
+    for (int q = 0; q < P; ++q) a += psum[q * C + tid];
+    mean[tid] = a / (float)Tn;
+  }
+  __syncthreads();
+  PRO_TM();
+  // logits + softmax by wave 0 (odconv.py:37-40)
+  if (wid == 0) {
+    if (areg) {
+      float lg[AK];
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            wv[r] = *reinterpret_cast<const uint4*>(film_w + (long)(j0 + r < F2 ? j0 + r : F2 - 1) * cond_dim + pc * EPV);
+      for (int k = 0; k < AK; ++k) {
+        lg[k] = 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            alignas(16) T tmp[EPV];
-            *reinterpret_cast<uint4*>(tmp) = wv[r];
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) a[r] += ld<T>(tmp + e) * cond[pc * EPV + e];
-          }
-        }
-      } else {
-        for (int i = lane; i < cond_dim; i += 64)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] += ld<T>(film_w + (long)(j0 + r < F2 ? j0 + r : F2 - 1) * cond_dim + i) * cond[i];
+        for (int i = 0; i < AWN; ++i) if (lane + 64 * i < C) lg[k] += aw[k][i] * mean[lane + 64 * i];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = wave_sum(a[r]);
-        if (lane == 0 && j0 + r < F2) st<T>(film_proj + (long)b * F2 + j0 + r, v + (film_b ? ld<T>(film_b + j0 + r) : 0.f));
+      for (int k = 0; k < AK; ++k) lg[k] = wave_sum(lg[k]) + ab[k];
+      float m = -INFINITY, den = 0.f;
+#pragma unroll
+      for (int k = 0; k < AK; ++k) if (k < K) m = fmaxf(m, lg[k]);
+#pragma unroll
+      for (int k = 0; k < AK; ++k) { lg[k] = k < K ? expf(lg[k] - m) : 0.f; den += lg[k]; }
+      if (lane < K) {
+        float v = lg[0];
+#pragma unroll
+        for (int k = 1; k < AK; ++k) v = lane == k ? lg[k] : v;
+        alpha[(long)b * K + lane] = v / den;
       }
+    } else {                              // any K <= 64: lane k ends up with logit k
+      float mine = -INFINITY;
+      for (int k = 0; k < K; ++k) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += ld<T>(att_w + (long)k * C + c) * mean[c];
+        a = wave_sum(a) + (att_b ? ld<T>(att_b + k) : 0.f);
+        if (lane == k) mine = a;
+      }
+      const float m = wave_max(mine);
+      const float e = lane < K ? expf(mine - m) : 0.f;
+      const float den = wave_sum(e);
+      if (lane < K) alpha[(long)b * K + lane] = e / den;
     }
   }
-  __syncthreads();
-  for (int k = wid; k < K; k += nw) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += ld<T>(att_w + (long)k * C + c) * mean[c];
-    a = wave_sum(a);
-    if (lane == 0) logit[k] = a + (att_b ? ld<T>(att_b + k) : 0.f);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    float m = -INFINITY, den = 0.f;
-    for (int k = 0; k < K; ++k) m = fmaxf(m, logit[k]);
-    for (int k = 0; k < K; ++k) den += expf(logit[k] - m);
-    for (int k = 0; k < K; ++k) alpha[(long)b * K + k] = expf(logit[k] - m) / den;
-  }
+#ifdef MV_PRO_TIMING
+  PRO_TM();
+  if (tid == 0 && pro_dbg) for (int i = 0; i < 8; ++i) pro_dbg[b * 8 + i] = i < ntm ? tmk[i] - tmk[0] : -1;
+#endif
 }
 
 // ---------------------------------------------------------------- GroupNorm
@@ -511,12 +605,34 @@ extern "C" int mv_gen_prologue(const void* mel, const void* att_w, const void* a
                                long zero_n, int B, int C, int T_, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream) {
   MV_CHECK_ARG(mel && att_w && alpha && x_cl && B > 0 && C > 0 && T_ > 0 && K > 0 && K <= 64 && ds >= 0 && de >= 0 && zero_n >= 0);
   MV_CHECK_ARG((ds == 0 || spk) && (de == 0 || emo) && (!film_proj || (film_w && cond_dim > 0 && F2 > 0)) && (zero_n == 0 || zero_buf));
-  const size_t lds = sizeof(float) * ((size_t)C * T_ + C + K + (film_proj ? cond_dim : 0));
+  constexpr int NT = 1024, NW = NT / 64;
+  if (C > NT) return MV_ERR_UNSUPPORTED;
+  const size_t lds_sample = sizeof(float) * ((size_t)C * (T_ | 1) + (size_t)(NT / C) * C + C);
+  const size_t lds_film = film_proj ? sizeof(float) * (size_t)PRO_SG * cond_dim : 0;
+  const size_t lds = lds_sample > lds_film ? lds_sample : lds_film;
   if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;   // long inputs: the caller issues the separate launches
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B), dim3(1024), lds, (hipStream_t)stream, (const T*)mel,
+  const int n_film = film_proj ? ((F2 + NW - 1) / NW) * ((B + PRO_SG - 1) / PRO_SG) : 0;
+#ifdef MV_PRO_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 1024 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(pro_dbg), &dbg, sizeof(dbg)); }
+#endif
+  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B + n_film), dim3(NT), lds, (hipStream_t)stream, (const T*)mel,
                                         (const T*)att_w, (const T*)att_b, (const T*)spk, (const T*)emo, (const T*)film_w,
-                                        (const T*)film_b, alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, C, T_, K, ds, de,
+                                        (const T*)film_b, alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, B, C, T_, K, ds, de,
                                         film_proj ? cond_dim : 0, F2));
+#ifdef MV_PRO_TIMING
+  if (++calls == 2 && B <= 1024) {
+    hipStreamSynchronize((hipStream_t)stream);
+    static long long hbuf[1024 * 8];
+    hipMemcpy(hbuf, dbg, sizeof(long long) * 8 * B, hipMemcpyDeviceToHost);
+    double avg[8] = {0};
+    for (int w = 0; w < B; ++w) for (int i = 0; i < 8; ++i) avg[i] += (double)hbuf[w * 8 + i] / B;
+    fprintf(stderr, "[prologue timing] dtype %d marks (start, mel issued, film, sync1, copy, means+sync2, logits+softmax):", dtype);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %.0f", avg[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

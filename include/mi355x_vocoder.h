@@ -215,10 +215,10 @@ int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const 
  * count follows the kernel variant the dispatcher picks for this geometry. */
 size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
                                 int transposed, int K, int act, int has_film, int dtype);
-/* Generator prologue in one launch (one workgroup per sample): input_proj's attention alpha fp32 [B][K] (odconv.py:36-40),
- * mel [B][C][T] -> x_cl [B][T][C], the FiLM projection film_proj [B][F2] = W cond + b with cond = cat(spk [B][ds], emo [B][de])
- * truncated / zero-padded to cond_dim (grc_lora.py:82-105; film_proj NULL = no conditioning), and zeroing of zero_buf[0..zero_n)
- * (the pooled-sum buffers of the upsamplers).  MV_ERR_UNSUPPORTED when one sample does not fit LDS. */
+/* Generator prologue in one launch: input_proj's attention alpha fp32 [B][K] (odconv.py:36-40) and mel [B][C][T] -> x_cl [B][T][C]
+ * (one workgroup per sample), the FiLM projection film_proj [B][F2] = W cond + b with cond = cat(spk [B][ds], emo [B][de])
+ * truncated / zero-padded to cond_dim (grc_lora.py:82-105; film_proj NULL = no conditioning; extra workgroups of the same grid,
+ * one per (16 rows, 8 samples)), and zeroing of zero_buf[0..zero_n).  MV_ERR_UNSUPPORTED when one sample does not fit LDS. */
 int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo, const void* film_w,
                     const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf, long zero_n, int B, int C,
                     int T, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream);
