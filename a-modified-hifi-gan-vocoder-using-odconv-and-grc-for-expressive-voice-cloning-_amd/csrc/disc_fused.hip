@@ -17,6 +17,9 @@
 
 namespace mv {
 
+#ifdef MV_DC_TIMING
+__device__ long long* dc_dbg = nullptr;
+#endif
 struct DcP {
   int B, H, W, Cin, Cout, kh, kw, act;
   float slope;
@@ -807,7 +810,17 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
     __syncthreads();
     buf ^= 1;
   }
-  if (do_gb && o0 + (tid & 63) < Cout) atomicAdd(gb + o0 + (tid & 63), bsum);
+  if (do_gb) {                                              // the 8 row-slice sums of a channel -> one atomic per channel and workgroup
+    float* red = reinterpret_cast<float*>(lds);            // (the loop's last barrier is behind us)
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 64 && o0 + tid < Cout) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sacc += red[r * 64 + tid];
+      atomicAdd(gb + o0 + tid, sacc);
+    }
+  }
   if (sample_stride > 0) gws += (long)(cbeg / (H * wsplit)) * sample_stride;
   // D[row = o (4*grp + r)][col = c (li)] -> gws[tap][o][c]
 #pragma unroll
@@ -819,6 +832,220 @@ __global__ __launch_bounds__(512) void dconv_wgrad_kernel(const T* __restrict__ 
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
         const int o = o0 + wm * 32 + m * 16 + 4 * grp, c = c0 + wn * 32 + n * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (o + r < Cout && c < Cin) atomicAdd(gws + ((long)tap * Cout + o + r) * Cin + c, acc[t][m][n][r]);
+      }
+  }
+}
+
+// 3x3 (dilation 1) weight gradient, second form.  The kernel above stages, per 64 positions of an image row, the three x rows
+// h-1, h, h+1 and a 64 x 64 channel tile: 33 KB of loads and 197 KB of LDS reads for 40 MFMAs per wave - both paths saturate
+// long before the matrix pipe (128->256 layer: 23 % of the MFMA peak).  Here
+//   * a workgroup walks its positions ROW AFTER ROW of one 64-column strip, so x rows stay in LDS: a ring of 8 row slots indexed
+//     by the "virtual row" v = strip * (H + 2) + h + 1 (every strip carries a zero row above and below); a step brings ONE new
+//     x row (two at a strip change) instead of three,
+//   * a wave owns MO = 4 M-tiles (64 output channels): LDS reads per MFMA 0.6 -> 0.35, g/x loads per MFMA 2.7x lower,
+//   * the tap split is 5 + 4 (the second wave half skips its fifth tap instead of multiplying a clamped copy).
+// Layout of the result and the final atomics are those of the kernel above.
+template <typename T, int MO>
+__global__ __launch_bounds__(512, 2) void dconv_wgrad3_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                              float* __restrict__ gws, float* __restrict__ gb, int B, int H, int W,
+                                                              int Cin, int Cout, int wsplit, int nchunks, int chunks_per_wg) {
+  static_assert(sizeof(T) == 2, "MFMA weight gradient needs 16-bit storage");
+  using M = Mma<T>;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  constexpr int WT = 64, XC = WT + 2, TAPS = 9, TPW = 5, OT = 32 * MO;
+  constexpr int RS = 160, RSG = OT * 2 + 32;                 // row strides: conflict-free transposed reads (stride = 32 mod 128)
+  constexpr int OPC = OT / 8, GP = WT * OPC, PP = XC * 8;    // 16-byte pieces: per g row, per g tile, per x row slot
+  constexpr int NLD = (GP + 2 * PP + 511) / 512;
+  constexpr int GBUF = WT * RSG, PBUF = XC * RS, XBASE = 2 * GBUF;
+  extern __shared__ __align__(16) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int th = wid >> 2, wm = (wid >> 1) & 1, wn = wid & 1;
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  const int o0 = blockIdx.y * OT, c0 = blockIdx.x * 64;
+  const int ntap = th ? TAPS - TPW : TPW;                    // 5 + 4
+  const int HV = H + 2;
+
+  f32x4 acc[TPW][MO][2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ga = (4 * grp + q) * RSG + (wm * MO * 16 + 4 * pp) * 2;
+  const int xa = (4 * grp + q) * RS + (wn * 32 + 4 * pp) * 2;
+  auto trload = [&](const char* p0, int stride) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p0 + 16 * stride));
+    const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    typename M::V r;
+    r.v = __builtin_bit_cast(decltype(r.v), both);
+    return r;
+  };
+  // x rows live in slots 0..7 (slot = virtual row & 7); slot 8 is a row of zeros that stands for every padding row
+  constexpr int ZSLOT = 8;
+  u32x4 pre[NLD];
+  // loads of: the g tile at (gb_, gh, gw0) when with_g, and up to two x rows (row index r0 / r1 of sample pb, strip column pw0;
+  // a negative row = none).  The piece -> (row, 16-byte column) maps are compile-time shifts; nothing here divides.
+  auto issue = [&](bool with_g, int gb_, int gh, int gw0, int pb, int pw0, int r0, int r1) {
+    const T* grow = g + (((long)gb_ * H + gh) * W + gw0) * Cout + o0;
+    const T* xrow0 = x + (((long)pb * H + (r0 < 0 ? 0 : r0)) * W + pw0 - 1) * Cin + c0;
+    const T* xrow1 = x + (((long)pb * H + (r1 < 0 ? 0 : r1)) * W + pw0 - 1) * Cin + c0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 512;
+      pre[i] = u32x4{0u, 0u, 0u, 0u};
+      if (idx < GP) {
+        const int r = idx / OPC, ch = idx - r * OPC;
+        if (with_g && gw0 + r < W && o0 + ch * 8 < Cout) pre[i] = *reinterpret_cast<const u32x4*>(grow + r * Cout + ch * 8);
+      } else if (idx < GP + 2 * PP) {
+        const int j = idx - GP;
+        const int sel = j >= PP ? 1 : 0, rr = j - sel * PP;
+        const int col = rr >> 3, ch = rr & 7;
+        const int ww = pw0 - 1 + col;
+        if ((sel ? r1 : r0) >= 0 && ww >= 0 && ww < W && c0 + ch * 8 < Cin)
+          pre[i] = *reinterpret_cast<const u32x4*>((sel ? xrow1 : xrow0) + col * Cin + ch * 8);
+      }
+    }
+  };
+  auto commit = [&](bool with_g, int gbuf, int s0, int s1) {      // s0 / s1: destination slots of the two rows (negative = none)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 512;
+      if (idx < GP) {
+        if (with_g) { const int r = idx / OPC, ch = idx - r * OPC; *reinterpret_cast<u32x4*>(lds + gbuf * GBUF + r * RSG + ch * 16) = pre[i]; }
+      } else if (idx < GP + 2 * PP) {
+        const int j = idx - GP;
+        const int sel = j >= PP ? 1 : 0, rr = j - sel * PP;
+        const int sl = sel ? s1 : s0;
+        if (sl >= 0) *reinterpret_cast<u32x4*>(lds + XBASE + sl * PBUF + (rr >> 3) * RS + (rr & 7) * 16) = pre[i];
+      }
+    }
+  };
+
+  const bool do_gb = gb != nullptr && blockIdx.x == 0;
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+  const int cbeg = blockIdx.z * chunks_per_wg;
+  int cend = cbeg + chunks_per_wg; if (cend > nchunks) cend = nchunks;
+  if (cbeg >= cend) return;
+  // chunk = (sample b, strip wc, row h), rows fastest; v = virtual row of h (each strip: zero row, H rows, zero row)
+  int b, wc, h, v;
+  {
+    const int st = cbeg / H;
+    h = cbeg - st * H;
+    b = st / wsplit;
+    wc = st - b * wsplit;
+    v = st * HV + h + 1;
+    for (int k = tid; k < PP; k += 512) *reinterpret_cast<u32x4*>(lds + XBASE + ZSLOT * PBUF + (k >> 3) * RS + (k & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+    issue(true, b, h, wc * WT, b, wc * WT, h > 0 ? h - 1 : -1, h);
+    commit(true, 0, h > 0 ? ((v - 1) & 7) : -1, v & 7);
+    issue(false, b, h, wc * WT, b, wc * WT, h + 1 < H ? h + 1 : -1, -1);
+    commit(false, 0, h + 1 < H ? ((v + 1) & 7) : -1, -1);
+  }
+  __syncthreads();
+  int par = 0;
+#ifdef MV_DC_TIMING
+  long long tacc[5] = {0, 0, 0, 0, 0}, tprev = clock64(), tnow;
+#define W3_TM(i) do { tnow = clock64(); tacc[i] += tnow - tprev; tprev = tnow; } while (0)
+#else
+#define W3_TM(i) do {} while (0)
+#endif
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const bool more = chunk + 1 < cend;                     // uniform across the workgroup
+    // the next chunk and the x rows it adds: one row below in the same strip, or rows 0 and 1 of the next strip
+    int nb = b, nwc = wc, nh = h + 1, nv = v + 1, r0, r1, s0, s1;
+    if (nh == H) { nh = 0; nv = v + 3; if (++nwc == wsplit) { nwc = 0; ++nb; } r0 = 0; r1 = H > 1 ? 1 : -1; s0 = nv & 7; s1 = H > 1 ? ((nv + 1) & 7) : -1; }
+    else { r0 = nh + 1 < H ? nh + 1 : -1; r1 = -1; s0 = r0 >= 0 ? ((nv + 1) & 7) : -1; s1 = -1; }
+    if (more) issue(true, nb, nh, nwc * WT, nb, nwc * WT, r0, r1);
+    int toff[TPW];                                          // wave-uniform LDS offset of each tap's shifted x window
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tap = (th * TPW + t) < TAPS ? (th * TPW + t) : (TAPS - 1);
+      const int ih = tap / 3, iw = tap - 3 * ih;
+      const int hh = h - 1 + ih;
+      toff[t] = XBASE + ((hh >= 0 && hh < H) ? ((v - 1 + ih) & 7) : ZSLOT) * PBUF + iw * RS;
+    }
+    const char* gbase = lds + par * GBUF;
+    W3_TM(0);
+    if (do_gb) {                                            // bias gradient from the staged g tile: 8 channels x 2 rows per thread
+      constexpr int RPP = 512 / OPC;
+#pragma unroll
+      for (int i = 0; i < WT / RPP; ++i) {
+        alignas(16) T tmp[8];
+        *reinterpret_cast<u32x4*>(tmp) = *reinterpret_cast<const u32x4*>(gbase + ((tid / OPC) + RPP * i) * RSG + (tid % OPC) * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += ld<T>(tmp + e);
+      }
+    }
+    W3_TM(1);
+#pragma unroll 1
+    for (int k0 = 0; k0 < WT; k0 += 32) {
+      typename M::V a[MO];
+#pragma unroll
+      for (int m = 0; m < MO; ++m) a[m] = trload(gbase + ga + k0 * RSG + m * 32, RSG);
+      constexpr int BT = 2;
+#pragma unroll
+      for (int tb = 0; tb < TPW; tb += BT) {
+        if (tb < ntap) {
+          typename M::V bfr[BT][2];
+#pragma unroll
+          for (int t = 0; t < BT; ++t)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              if (tb + t < TPW) bfr[t][n] = trload(lds + toff[tb + t] + xa + k0 * RS + n * 32, RS);
+#pragma unroll
+          for (int t = 0; t < BT; ++t)
+            if (tb + t < TPW && tb + t < ntap) {
+#pragma unroll
+              for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < MO; ++m) acc[tb + t][m][n] = M::mma(a[m], bfr[t][n], acc[tb + t][m][n]);
+            }
+        }
+      }
+    }
+    W3_TM(2);
+    if (more) commit(true, par ^ 1, s0, s1);
+    W3_TM(3);
+    __syncthreads();
+    W3_TM(4);
+    par ^= 1;
+    b = nb; wc = nwc; h = nh; v = nv;
+  }
+#ifdef MV_DC_TIMING
+  if (tid == 0 && dc_dbg) {
+    const long wgid = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (wgid < 4096) { for (int i = 0; i < 5; ++i) dc_dbg[wgid * 8 + i] = tacc[i] / (cend - cbeg); dc_dbg[wgid * 8 + 5] = cend - cbeg; dc_dbg[wgid * 8 + 6] = dc_dbg[wgid * 8 + 7] = -1; }
+  }
+#endif
+  if (do_gb) {                                              // row-slice sums -> one atomic per channel and workgroup
+    float* red = reinterpret_cast<float*>(lds);            // [512 / OPC slices][OT] (the loop's last barrier is behind us)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(tid / OPC) * OT + (tid % OPC) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < OT && o0 + tid < Cout) {
+      float sacc = 0.f;
+      for (int r = 0; r < 512 / OPC; ++r) sacc += red[r * OT + tid];
+      atomicAdd(gb + o0 + tid, sacc);
+    }
+  }
+  // D[row = o (4*grp + r)][col = c (li)] -> gws[tap][o][c]
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = th * TPW + t;
+    if (tap >= TAPS) continue;
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int o = o0 + wm * MO * 16 + m * 16 + 4 * grp, c = c0 + wn * 32 + n * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (o + r < Cout && c < Cin) atomicAdd(gws + ((long)tap * Cout + o + r) * Cin + c, acc[t][m][n][r]);
@@ -1273,9 +1500,56 @@ static int dwgrad_launch(const void* x, const void* g, float* gws, float* gb, in
   return MV_OK;
 }
 
+#ifdef MV_DC_TIMING
+static void w3_dump(int mo, dim3 grid, hipStream_t st) {
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { (void)hipMalloc(&dbg, 4096 * 8 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(dc_dbg), &dbg, sizeof(dbg)); return; }
+  if (++calls % 13 != 5) return;
+  (void)hipStreamSynchronize(st);
+  static long long hbuf[4096 * 8];
+  (void)hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+  const long nwg = (long)grid.x * grid.y * grid.z < 4096 ? (long)grid.x * grid.y * grid.z : 4096;
+  double avg[8] = {0}; int cnt[8] = {0};
+  for (long w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) { long long v = hbuf[w * 8 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
+  fprintf(stderr, "[wgrad3 timing] MO %d grid %u x %u x %u per chunk (issue+toff, bias, mfma, commit, barrier, chunks):", mo, grid.x, grid.y, grid.z);
+  for (int i = 0; i < 8; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
+  fprintf(stderr, "\n");
+}
+#endif
+template <typename T, int MO>
+static int dwgrad3_launch(const void* x, const void* g, float* gws, float* gb, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+  constexpr int WT = 64, OT = 32 * MO;
+  const int wsplit = cdiv(W, WT);
+  const size_t lds = 2 * (size_t)WT * (OT * 2 + 32) + 9 * (size_t)(WT + 2) * 160;
+  auto kern = dconv_wgrad3_kernel<T, MO>;
+  static bool lds_set = false;
+  if (!lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = true; }
+  const long nchunks = (long)B * wsplit * H;               // chunk = (sample, strip, row), rows fastest
+  if (nchunks > (1L << 30) || (long)B * wsplit * (H + 2) > (1L << 30)) return MV_ERR_UNSUPPORTED;
+  const int tiles = cdiv(Cin, 64) * cdiv(Cout, OT);
+  static int target = 0;
+  if (!target) { const char* e = getenv("MV_WGRAD_WGS"); target = e ? atoi(e) : 256; if (target < 1) target = 256; }
+  int groups = target / tiles; if (groups < 1) groups = 1; if (groups > nchunks) groups = (int)nchunks;
+  const int cpw = (int)((nchunks + groups - 1) / groups);
+  groups = (int)((nchunks + cpw - 1) / cpw);
+  if (groups > 65535) return MV_ERR_UNSUPPORTED;
+  dim3 grid(cdiv(Cin, 64), cdiv(Cout, OT), groups);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, (const T*)x, (const T*)g, gws, gb, B, H, W, Cin, Cout, wsplit, (int)nchunks, cpw);
+#ifdef MV_DC_TIMING
+  w3_dump(MO, grid, s);
+#endif
+  return MV_OK;
+}
+
 template <typename T>
 static int dwgrad_dispatch(const void* x, const void* g, float* ws, float* gb, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                            int dil, hipStream_t s) {
+  if (kh == 3 && kw == 3 && dil == 1) {
+    static int v3 = -1;
+    if (v3 < 0) { const char* e = getenv("MV_WGRAD3"); v3 = e ? atoi(e) : 1; }
+    if (v3) return Cout >= 128 ? dwgrad3_launch<T, 4>(x, g, ws, gb, B, H, W, Cin, Cout, s) : dwgrad3_launch<T, 2>(x, g, ws, gb, B, H, W, Cin, Cout, s);
+  }
   if (kh == 3 && kw == 3) return dil == 1 ? dwgrad_launch<T, 3, 3, 64>(x, g, ws, gb, B, H, W, Cin, Cout, 1, s) : MV_ERR_UNSUPPORTED;
   if (kh != 1) return MV_ERR_UNSUPPORTED;
   switch (kw) {
