@@ -214,13 +214,13 @@ __global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict_
 // for 4 column blocks and 4 waves per CU (one wave per SIMD, nothing to hide latency behind).  Here the input is staged in
 // 128-channel chunks, the tile keeps 128 positions, and 8 waves split it as 2 position halves x 4 row groups (2 M-tiles x 4
 // column blocks each): two waves per SIMD on the same LDS budget.  Weight k-steps are fetched two ahead, across chunks.
-template <typename T, int PS, int MW, int NB, int CCH>
-__global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+template <typename T, int PS, int MW, int NB, int CCH, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_wide_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                             const T* __restrict__ bias, const T* __restrict__ actsave,
                                                             T* __restrict__ y, DcP p) {
   using M = Mma<T>;
   using V = typename M::V;
-  constexpr int ES = M::ES, RG = 8 / PS, NPOS = PS * NB * 16;   // PS position slices x RG row groups = 8 waves; CCH channels staged at a time
+  constexpr int ES = M::ES, RG = NWV / PS, NPOS = PS * NB * 16, NT = NWV * 64;   // PS position slices x RG row groups = NWV waves; CCH channels staged at a time
   extern __shared__ __align__(16) char lds[];
   const int RS = lds_row_stride(CCH * ES, ES);
   const int prow = NPOS + (p.kw - 1) * p.dil;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
 
   auto stage = [&](int ck) {
     constexpr int UB = 8;
-    constexpr int cpr = CCH * ES / 16, rpp = 512 / cpr;
+    constexpr int cpr = CCH * ES / 16, rpp = NT / cpr;
     const int ch = tid % cpr;
     const int nrow = p.kh * prow;
     const char* xb = reinterpret_cast<const char*>(x + (long)b * p.H * p.W * p.Cin + (long)ck * CCH) + ch * 16;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512) void dconv_cl_wide_kernel(const T* __restrict_
     constexpr int CPR = RW / EPC;
     T* yrow = y + (((long)b * p.H + h) * p.W) * p.Cout;
     const T* srow = actsave ? actsave + (((long)b * p.H + h) * p.W) * p.Cout : nullptr;
-    for (int i = tid; i < NPOS * CPR; i += 512) {
+    for (int i = tid; i < NPOS * CPR; i += NT) {
       const int ch = i % CPR, wi = i / CPR;
       const int ww = w0 + wi, row = R0 + ch * EPC;
       if (ww >= p.W || row >= p.Cout) continue;
@@ -1341,6 +1341,24 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
     // 3x3 layers with >= 128 channels on both sides: 256-position tiles (8 column blocks per wave: one weight fragment feeds
     // 8 MFMAs) with 64-channel chunks measured 6-13 % faster than 128-position tiles; the k15 layers measured slower
     const bool nb8 = kh == 3 && Cin % 64 == 0 && Cin >= 128 && Cout >= 128 && W >= 256;
+    // 4-wave form of the 256-row tile (MV_DCONV_W4=0 switches it off): 256 rows x 128 positions, 64-channel chunks, TWO workgroups per CU - one's
+    // staging and epilogue run under the other's MFMAs; every wave keeps the 64 x 128 tile of the 8-wave kernel
+    static int w4 = -1;
+    if (w4 < 0) { const char* e = getenv("MV_DCONV_W4"); w4 = e ? atoi(e) : 1; }
+    if (w4 && kh == 3 && Cin % 64 == 0 && Cout % 256 == 0 && W >= 128 && force != 0) {
+      p.cchunk = 64;
+      const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(64 * 2, 2);
+      const size_t ob = (size_t)128 * (256 * 2 + 16);
+      const size_t ldsb = xb > ob ? xb : ob;
+      dim3 grid(cdiv(W, 128), Cout / 256, B * H);
+#define MV_W4(TT) do { auto kern = dconv_cl_wide_kernel<TT, 1, 4, 8, 64, 4>; static size_t lds_set_4 = 0; \
+        if (ldsb > lds_set_4) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_4 = ldsb; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), ldsb, (hipStream_t)stream, (const TT*)x, (const TT*)packed, (const TT*)bias, (const TT*)act_save, (TT*)y, p); } while (0)
+      if (dtype == MV_BF16) MV_W4(bf16); else MV_W4(f16);
+#undef MV_W4
+      MV_LAUNCH_CHECK();
+      return MV_OK;
+    }
     const int npos = nb8 ? 256 : 128;
     p.cchunk = nb8 ? 64 : (Cin > 128 ? 128 : Cin);
     if (use && Cin % p.cchunk == 0 && (p.cchunk == 128 || p.cchunk == 64 || p.cchunk == 32)) {
