@@ -1359,6 +1359,25 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
       MV_LAUNCH_CHECK();
       return MV_OK;
     }
+    // 128-row outputs of the big 3x3 layers (the data gradient of 128->256): 2 waves per workgroup, each with the 64 x 128 tile;
+    // 32-channel chunks keep the tile at 37 KB, so FOUR workgroups share a CU (445 -> 425 us; 64 input channels measured slower).
+    // MV_DCONV_W2 = smallest Cin that takes this path (0: never)
+    static int w2 = -1;
+    if (w2 < 0) { const char* e = getenv("MV_DCONV_W2"); w2 = e ? atoi(e) : 128; }
+    if (w2 && kh == 3 && Cin % 32 == 0 && Cin >= w2 && Cout == 128 && W >= 128 && force != 0) {
+      p.cchunk = 32;
+      const size_t xb = (size_t)kh * (128 + (kw - 1) * dil_w) * lds_row_stride(32 * 2, 2);
+      const size_t ob = (size_t)128 * (128 * 2 + 16);
+      const size_t ldsb = xb > ob ? xb : ob;
+      dim3 grid(cdiv(W, 128), 1, B * H);
+#define MV_W2(TT) do { auto kern = dconv_cl_wide_kernel<TT, 1, 4, 8, 32, 2>; static size_t lds_set_2 = 0; \
+        if (ldsb > lds_set_2) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb); lds_set_2 = ldsb; } \
+        hipLaunchKernelGGL(kern, grid, dim3(128), ldsb, (hipStream_t)stream, (const TT*)x, (const TT*)packed, (const TT*)bias, (const TT*)act_save, (TT*)y, p); } while (0)
+      if (dtype == MV_BF16) MV_W2(bf16); else MV_W2(f16);
+#undef MV_W2
+      MV_LAUNCH_CHECK();
+      return MV_OK;
+    }
     const int npos = nb8 ? 256 : 128;
     p.cchunk = nb8 ? 64 : (Cin > 128 ? 128 : Cin);
     if (use && Cin % p.cchunk == 0 && (p.cchunk == 128 || p.cchunk == 64 || p.cchunk == 32)) {
