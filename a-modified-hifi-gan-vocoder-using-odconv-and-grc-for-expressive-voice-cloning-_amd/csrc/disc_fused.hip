@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void dconv_multi_pack_kernel(const MultiPackDe
 }
 
 template <typename T, int NWV, int MW, int NB>
-__global__ __launch_bounds__(NWV * 64) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+__global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                        const T* __restrict__ bias, const T* __restrict__ actsave,
                                                        T* __restrict__ y, DcP p) {
   using M = Mma<T>;
@@ -1411,7 +1411,11 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   }
   MV_DISPATCH(dtype, {
     hipStream_t s_ = (hipStream_t)stream;
-    if (Cout >= 256) {        // 8 waves cover all 256 rows: the x tile is staged once per column block
+    static int m4 = -1;
+    if (m4 < 0) { const char* e = getenv("MV_DCONV_M4"); m4 = e ? atoi(e) : 1; }
+    if (Cout >= 256 && m4) {  // 4 waves x 64 rows: one B fragment feeds 4 MFMAs (LDS reads per MFMA halved), two workgroups per CU
+      rc = dconv_launch<T, 4, 4, 8>(x, packed, bias, act_save, y, p, s_);
+    } else if (Cout >= 256) {        // 8 waves cover all 256 rows: the x tile is staged once per column block
       rc = dconv_launch<T, 8, 2, 8>(x, packed, bias, act_save, y, p, s_);
       if (rc == MV_ERR_UNSUPPORTED) rc = dconv_launch<T, 8, 2, 4>(x, packed, bias, act_save, y, p, s_);
     } else if (Cout >= 128) {
