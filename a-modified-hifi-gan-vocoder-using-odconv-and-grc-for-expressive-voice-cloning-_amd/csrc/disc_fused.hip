@@ -70,6 +70,25 @@ __global__ __launch_bounds__(256) void dconv_multi_pack_kernel(const MultiPackDe
   }
 }
 
+// XCD-aware tile order for the [B][H][W] convs.  Workgroups are dealt to the 8 XCDs round-robin by linear id, and every XCD has its own
+// L2; with the plain (W tile, row tile, b*H + h) grid the three workgroups that read the same input row (h-1, h, h+1 of a 3x3 conv)
+// sit gridDim.x ids apart - on different XCDs - and the row comes out of HBM / MALL once per XCD (PMC: the 256->128 data gradient
+// fetched 4.8x its input).  Here XCD k walks a contiguous range of the order (b, row tile, W tile, h) with h FASTEST, so the rows a
+// workgroup shares with its predecessor are in that XCD's L2.  The map is a bijection for any grid size (guide: section 5, XCD swizzle).
+struct TileId { int wx, ry, b, h; };
+__device__ __forceinline__ TileId xcd_tile(int H) {
+  const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
+  const unsigned L = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  const unsigned xcd = L & 7, j = L >> 3, q = nwg >> 3, r = nwg & 7;
+  unsigned LL = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  TileId t;
+  t.h = LL % H; LL /= H;
+  t.wx = LL % nx; LL /= nx;
+  t.ry = LL % ny;
+  t.b = LL / ny;
+  return t;
+}
+
 template <typename T, int NWV, int MW, int NB>
 __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
                                                        const T* __restrict__ bias, const T* __restrict__ actsave,
@@ -82,9 +101,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_kernel(const T* __restri
   const int prow = NB * 16 + (p.kw - 1) * p.dil;  // staged columns per plane
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const int w0 = blockIdx.x * NB * 16;
-  const int mt0 = (blockIdx.y * NWV + wid) * MW;
-  const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
+  const TileId tl = xcd_tile(p.H);
+  const int w0 = tl.wx * NB * 16;
+  const int mt0 = (tl.ry * NWV + wid) * MW;
+  const int b = tl.b, h = tl.h;
   const int n_mt = p.Cout / 16;
   const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
 
@@ -159,7 +179,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_kernel(const T* __restri
   __syncthreads();
   constexpr int RW = NWV * MW * 16;
   constexpr int ORS = RW * ES + 16;
-  const int R0 = blockIdx.y * RW;
+  const int R0 = tl.ry * RW;
   auto epi = [&](auto actf) {       // one body per activation kind: a run-time `act` in the element loop is a branch tree per element
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw) {
@@ -227,9 +247,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_wide_kernel(const T* __r
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
   const int ps = wid / RG, rg = wid % RG;                // position slice, row group
-  const int w0 = blockIdx.x * NPOS;
-  const int mt0 = (blockIdx.y * RG + rg) * MW;
-  const int bh = blockIdx.z, b = bh / p.H, h = bh % p.H;
+  const TileId tl = xcd_tile(p.H);
+  const int w0 = tl.wx * NPOS;
+  const int mt0 = (tl.ry * RG + rg) * MW;
+  const int b = tl.b, h = tl.h;
   const int n_mt = p.Cout / 16;
   const int ph = p.kh / 2, pw = (p.kw / 2) * p.dil;
   const int taps = p.kh * p.kw, nchunks = p.Cin / CCH;
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_wide_kernel(const T* __r
   __syncthreads();
   constexpr int RW = RG * MW * 16;
   constexpr int ORS = RW * ES + 16;
-  const int R0 = blockIdx.y * RW;
+  const int R0 = tl.ry * RW;
   auto epi = [&](auto actf) {
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw) {
