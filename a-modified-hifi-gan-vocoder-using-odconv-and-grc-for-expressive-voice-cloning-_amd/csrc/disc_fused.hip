@@ -26,6 +26,11 @@ struct DcP {
   int ksteps, cin32;
   int dil;                                        // dilation along W (1 for the discriminators; GRC convs use 1/3/5)
   int cchunk;                                     // wide variant: input channels staged in LDS at a time
+  // fused 256 -> 1 head (forward only; both null otherwise): after the epilogue tile is complete, z[tap][pos] = sum_c w[c][tap] * y[pos][c]
+  // for this workgroup's positions - dhead_z_kernel's result without reading y back from HBM (needs all 256 output rows in the workgroup)
+  const void* head_pf;                            // dhead_pack_kernel's forward operator [C/32][lane][8]
+  float* head_z;                                  // [16][B*H*W] per-tap partial sums
+  int head_taps;
 };
 
 // packed[mt][kstep][lane][8]: row o = 16*mt + lane&15, k-chunk = 4*kstep + lane>>4 -> tap = chunk / (Cin/8), c = 8*(chunk % (Cin/8)) + j
@@ -87,6 +92,31 @@ __device__ __forceinline__ TileId xcd_tile(int H) {
   t.ry = LL % ny;
   t.b = LL / ny;
   return t;
+}
+
+// the fused head pass of a conv epilogue: `tile` = LDS epilogue tile [NPOS positions][256 channels] (row stride ORS bytes), already activated
+template <typename T, int NPOS, int NWVS>
+__device__ __forceinline__ void dhead_from_tile(const char* tile, int ORS, const DcP& p, long rowbase, int w0, int wid, int lane) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int ES = M::ES, KS = 256 / 32;
+  const int col = lane & 15, g = lane >> 4;
+  const long npos = (long)p.B * p.H * p.W;
+  V a[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) a[ks] = M::load_b(reinterpret_cast<const char*>(p.head_pf) + ((long)ks * 64 + lane) * 16);
+  for (int pb = wid; pb < NPOS / 16; pb += NWVS) {
+    const char* xr = tile + (long)(pb * 16 + col) * ORS + 8 * g * ES;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = M::mma(a[ks], M::load_b(xr + ks * 32 * ES), acc);
+    const int ww = w0 + pb * 16 + col;
+    if (ww < p.W) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * g + r < p.head_taps) p.head_z[(long)(4 * g + r) * npos + rowbase + ww] = acc[r];
+    }
+  }
 }
 
 template <typename T, int NWV, int MW, int NB>
@@ -200,6 +230,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_kernel(const T* __restri
   };
   if (p.act <= ACT_LRELU) epi(ActLrelu{p.act == ACT_NONE ? 1.f : p.slope}); else epi(ActAny{p.act, p.slope});
   __syncthreads();
+  if constexpr (RW == 256 && ES == 2) {
+    if (p.head_pf) dhead_from_tile<T, NB * 16, NWV>(lds, ORS, p, ((long)b * p.H + h) * p.W, w0, wid, lane);
+  }
   {
     constexpr int EPC = 16 / ES;
     constexpr int CPR = RW / EPC;
@@ -360,6 +393,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void dconv_cl_wide_kernel(const T* __r
   };
   if (p.act <= ACT_LRELU) epi(ActLrelu{p.act == ACT_NONE ? 1.f : p.slope}); else epi(ActAny{p.act, p.slope});
   __syncthreads();
+  if constexpr (RW == 256 && ES == 2) {
+    if (p.head_pf) dhead_from_tile<T, NPOS, NWV>(lds, ORS, p, ((long)b * p.H + h) * p.W, w0, wid, lane);
+  }
   {
     constexpr int EPC = 16 / ES;
     constexpr int CPR = RW / EPC;
@@ -1342,13 +1378,14 @@ static int dconv_launch(const void* x, const void* wp, const void* bias, const v
   return MV_OK;
 }
 
-extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y,
-                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype,
-                               void* stream) {
+static int dconv_cl_fwd_impl(const void* x, const void* packed, const void* bias, const void* act_save, void* y,
+                             int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype,
+                             void* stream, const void* head_pf, float* head_z, int head_taps) {
   MV_CHECK_ARG(x && packed && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 16 == 0 && (kh & 1) && (kw & 1));
   MV_CHECK_ARG(dil_w >= 1 && (kw - 1) * dil_w <= 128);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0 && Cout % 8 == 0);
-  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w, Cin};
+  if (head_pf && (Cout != 256 || dtype == MV_F32 || act_save || B * H > 65535)) return MV_ERR_UNSUPPORTED;   // needs the 256-row workgroups
+  DcP p{B, H, W, Cin, Cout, kh, kw, act, slope, kh * kw * (Cin / 32), Cin / 32, dil_w, Cin, head_pf, head_z, head_taps};
   int rc = MV_ERR_DTYPE;
   if (dtype != MV_F32 && B * H <= 65535) {
     // 8-wave chunked variant: picked where it measured faster than the whole-Cin tile (tools/bench_dconv.py, B=32):
@@ -1359,6 +1396,7 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
     const bool big3x3 = kh == 3 && Cin == 128 && Cout >= 256;      // 256 rows per workgroup: 4 M-tiles per B fragment
     bool use = full > 160 * 1024 || Cin > 128 || (kh == 3 && Cin >= 64 && Cout <= 128) || (kh == 1 && Cin == 64 && Cout == 32) || big3x3;
     if (force >= 0) use = force != 0;
+    if (head_pf && !(big3x3 || (kh == 3 && Cin % 64 == 0 && Cin >= 128 && W >= 256))) use = false;   // the chunked tiles below have 256 rows only there
     // 3x3 layers with >= 128 channels on both sides: 256-position tiles (8 column blocks per wave: one weight fragment feeds
     // 8 MFMAs) with 64-channel chunks measured 6-13 % faster than 128-position tiles; the k15 layers measured slower
     const bool nb8 = kh == 3 && Cin % 64 == 0 && Cin >= 128 && Cout >= 128 && W >= 256;
@@ -1452,6 +1490,20 @@ extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bi
   return MV_OK;
 }
 
+extern "C" int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const void* act_save, void* y,
+                               int B, int H, int W, int Cin, int Cout, int kh, int kw, int dil_w, int act, float slope, int dtype,
+                               void* stream) {
+  return dconv_cl_fwd_impl(x, packed, bias, act_save, y, B, H, W, Cin, Cout, kh, kw, dil_w, act, slope, dtype, stream, nullptr, nullptr, 0);
+}
+
+extern "C" int mv_dconv_cl_fwd_head(const void* x, const void* packed, const void* bias, void* y, const void* head_packed, float* head_ws,
+                                    int head_kh, int head_kw, int B, int H, int W, int Cin, int Cout, int kh, int kw, int act, float slope,
+                                    int dtype, void* stream) {
+  MV_CHECK_ARG(head_packed && head_ws && head_kh > 0 && head_kw > 0 && head_kh * head_kw <= 16 && ((uintptr_t)head_packed & 15) == 0);
+  return dconv_cl_fwd_impl(x, packed, bias, nullptr, y, B, H, W, Cin, Cout, kh, kw, 1, act, slope, dtype, stream, head_packed, head_ws,
+                           head_kh * head_kw);
+}
+
 extern "C" size_t mv_dhead_packed_bytes(int C, int dtype) { return (size_t)(C / 32 + C / 16) * 512 * (dtype == MV_F32 ? 4 : 2); }
 extern "C" size_t mv_dhead_workspace_bytes(int B, int H, int W) { return sizeof(float) * 16 * (size_t)B * H * W; }
 
@@ -1487,6 +1539,17 @@ extern "C" int mv_dhead_fwd(const void* x, const void* packed, const void* bias,
   MV_CHECK_ARG(x && packed && workspace && y && B > 0 && H > 0 && W > 0 && C == DH_C && kh * kw <= 16 && ((uintptr_t)x & 15) == 0);
   if (dtype == MV_BF16) dhead_fwd_launch<bf16>(x, packed, bias, workspace, y, B, H, W, kh, kw, (hipStream_t)stream);
   else if (dtype == MV_F16) dhead_fwd_launch<f16>(x, packed, bias, workspace, y, B, H, W, kh, kw, (hipStream_t)stream);
+  else return MV_ERR_UNSUPPORTED;
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_dhead_sum(const float* workspace, const void* bias, void* y, int B, int H, int W, int kh, int kw, int dtype, void* stream) {
+  MV_CHECK_ARG(workspace && y && B > 0 && H > 0 && W > 0 && kh * kw <= 16);
+  const long npos = (long)B * H * W;
+  const unsigned grid = (unsigned)((npos + 255) / 256 > 4096 ? 4096 : (npos + 255) / 256);
+  if (dtype == MV_BF16) hipLaunchKernelGGL(dhead_sum_kernel<bf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, workspace, (const bf16*)bias, (bf16*)y, B, H, W, kh, kw, 0);
+  else if (dtype == MV_F16) hipLaunchKernelGGL(dhead_sum_kernel<f16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, workspace, (const f16*)bias, (f16*)y, B, H, W, kh, kw, 0);
   else return MV_ERR_UNSUPPORTED;
   MV_LAUNCH_CHECK();
   return MV_OK;

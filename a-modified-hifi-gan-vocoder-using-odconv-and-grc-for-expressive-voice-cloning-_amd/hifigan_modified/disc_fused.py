@@ -149,17 +149,32 @@ class _DiscStack(Function):
         a = torch.empty(B, H, W, C1, device=dev, dtype=dt)
         N.call("mv_dfirst_fwd_cl", _P(x0), _P(cast(params[0])), _P(cast(bs[0])), _P(a), B, H, W, C1, kh, kw, float(slope), ops._dt(x0), st())
         acts.append(a)
+        C4 = ws[4].shape[1]
+        hkh, hkw = ws[4].shape[2], ws[4].shape[3]
+        mfma_head = C4 == 256 and hkh * hkw <= 16
+        zws, head_fused = None, False
         for li in (1, 2, 3):
             Cout, Cin = ws[li].shape[0], ws[li].shape[1]
             y = torch.empty(B, H, W, Cout, device=dev, dtype=dt)
-            N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(params[2 * li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
-                   kh, kw, 1, N.ACT_LRELU, float(slope), ops._dt(x0), st())
+            if li == 3 and mfma_head and Cout == 256 and dt != torch.float32:
+                # the head's per-tap partial sums come out of the last conv's epilogue tile (LDS): its 256-channel output is not read back
+                zws = torch.empty(16, B * H * W, device=dev, dtype=torch.float32)
+                rc = N.lib().mv_dconv_cl_fwd_head(_P(acts[-1]), _P(_packs.get(params[2 * li], dt, 0)), _P(cast(bs[li])), _P(y),
+                                                  _P(_packs.head_mfma(params[8], dt)), _P(zws), hkh, hkw, B, H, W, Cin, Cout, kh, kw,
+                                                  N.ACT_LRELU, float(slope), ops._dt(x0), st())
+                if rc != -3:            # MV_ERR_UNSUPPORTED: no 256-row variant for this geometry - separate launches below
+                    N.check(rc, "mv_dconv_cl_fwd_head")
+                    head_fused = True
+            if not (li == 3 and head_fused):
+                N.call("mv_dconv_cl_fwd", _P(acts[-1]), _P(_packs.get(params[2 * li], dt, 0)), _P(cast(bs[li])), None, _P(y), B, H, W, Cin, Cout,
+                       kh, kw, 1, N.ACT_LRELU, float(slope), ops._dt(x0), st())
             acts.append(y)
-        C4 = ws[4].shape[1]
         out = torch.empty((B, 1, H, W) if x0.dim() == 4 else (B, 1, W), device=dev, dtype=dt)
-        if C4 == 256 and kh * kw <= 16:
+        if head_fused:
+            N.call("mv_dhead_sum", _P(zws), _P(cast(bs[4])), _P(out), B, H, W, hkh, hkw, ops._dt(x0), st())
+        elif mfma_head:
             # head (C4 -> 1): taps on the MFMA rows, x read once (mv_dhead_fwd)
-            zws = torch.empty(16, B * H * W, device=dev, dtype=torch.float32)
+            zws = torch.empty(16, B * H * W, device=dev, dtype=torch.float32) if zws is None else zws
             N.call("mv_dhead_fwd", _P(acts[-1]), _P(_packs.head_mfma(params[8], dt)), _P(cast(bs[4])), _P(zws), _P(out), B, H, W, C4,
                    kh, kw, ops._dt(x0), st())
         else:

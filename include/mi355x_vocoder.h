@@ -352,6 +352,15 @@ int mv_dconv_cl_fwd(const void* x, const void* packed, const void* bias, const v
  *   mv_dhead_pack: w [1][C][kh][kw] -> forward + data-gradient operators (mv_dhead_packed_bytes).
  *   mv_dhead_fwd:  y [B][H][W] = bias[0] + conv(x [B][H][W][C]); workspace: mv_dhead_workspace_bytes (per-tap partial sums).
  *   mv_dhead_dgrad: gx [B][H][W][C] = LeakyReLU'(xsave) * conv^T(g [B][H][W]). */
+/*   mv_dconv_cl_fwd_head: mv_dconv_cl_fwd (dilation 1, no act_save) of the LAST hidden layer (Cout = 256) that also leaves the head's
+ *                  per-tap partial sums in head_ws, computed from the output tile while it is still in LDS - the head forward without
+ *                  reading the 256-channel activation back from HBM (discriminators.py:65 / :106 applied to :57-64 / :97-105).
+ *                  head_packed: mv_dhead_pack's buffer.  MV_ERR_UNSUPPORTED when the geometry has no 256-row workgroup variant.
+ *   mv_dhead_sum:  y [B][H][W] = bias[0] + shifted sum of the per-tap partial sums (the second half of mv_dhead_fwd). */
+int mv_dconv_cl_fwd_head(const void* x, const void* packed, const void* bias, void* y, const void* head_packed, float* head_ws,
+                         int head_kh, int head_kw, int B, int H, int W, int Cin, int Cout, int kh, int kw, int act, float slope,
+                         int dtype, void* stream);
+int mv_dhead_sum(const float* workspace, const void* bias, void* y, int B, int H, int W, int kh, int kw, int dtype, void* stream);
 size_t mv_dhead_packed_bytes(int C, int dtype);
 size_t mv_dhead_workspace_bytes(int B, int H, int W);
 int mv_dhead_pack(const void* w, int param_dtype, void* packed, int C, int kh, int kw, int dtype, void* stream);

@@ -463,3 +463,39 @@ def test_mel_loss_fft_and_dft_paths_vs_oracle(H, n_fft, hop, n_mels, sr, T, kind
     assert O.rel_l2(w.grad.cpu(), w_ref.grad.float()) < 2e-3
     mel = Fn.mel_spectrogram(wave.cuda(), fb, n_fft=n_fft, hop=hop)
     assert O.rel_l2(mel.cpu(), O.mel_spectrogram(wave.double(), **kw).float()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H_,W,kh,kw", [(7, 300, 3, 3), (2, 129, 3, 3), (1, 515, 1, 15), (11, 128, 3, 3)])
+def test_head_partial_sums_from_the_conv_epilogue(H, dtype, H_, W, kh, kw):
+    """mv_dconv_cl_fwd_head (last hidden conv 128->256 + the head's per-tap partial sums out of its LDS epilogue tile, then mv_dhead_sum)
+    against the separate launches mv_dconv_cl_fwd + mv_dhead_fwd (discriminators.py:63-65 / :104-106): same activation, and - the
+    MFMAs see the same rounded operands in the same order - the same head output bit for bit."""
+    from ctypes import c_void_p
+    from hifigan_modified import _native as N, ops, disc_fused
+    torch.manual_seed(3)
+    B, Cin, Cout = 3, 128, 256
+    x = torch.randn(B, H_, W, Cin, device="cuda").to(dtype)
+    w4 = torch.nn.Parameter(torch.randn(Cout, Cin, kh, kw, device="cuda") / (Cin * kh * kw) ** 0.5)
+    b4 = (torch.randn(Cout, device="cuda") * 0.1).to(dtype)
+    w5 = torch.nn.Parameter(torch.randn(1, Cout, kh, kw, device="cuda") / (Cout * kh * kw) ** 0.5)
+    b5 = torch.randn(1, device="cuda").to(dtype)
+    P = lambda t: c_void_p(t.data_ptr())
+    pk = disc_fused._packs.get(w4, dtype, 0)
+    hp = disc_fused._packs.head_mfma(w5, dtype)
+    dt, st = ops._dt(x), ops._stream()
+    y0 = torch.empty(B, H_, W, Cout, device="cuda", dtype=dtype)
+    z0 = torch.zeros(16, B * H_ * W, device="cuda")
+    o0 = torch.empty(B, H_, W, device="cuda", dtype=dtype)
+    N.call("mv_dconv_cl_fwd", P(x), P(pk), P(b4), None, P(y0), B, H_, W, Cin, Cout, kh, kw, 1, N.ACT_LRELU, 0.1, dt, st)
+    N.call("mv_dhead_fwd", P(y0), P(hp), P(b5), P(z0), P(o0), B, H_, W, Cout, kh, kw, dt, st)
+    y1 = torch.empty_like(y0)
+    z1 = torch.zeros_like(z0)
+    o1 = torch.empty_like(o0)
+    rc = N.lib().mv_dconv_cl_fwd_head(P(x), P(pk), P(b4), P(y1), P(hp), P(z1), kh, kw, B, H_, W, Cin, Cout, kh, kw, N.ACT_LRELU, 0.1, dt, st)
+    assert rc == 0, rc
+    N.call("mv_dhead_sum", P(z1), P(b5), P(o1), B, H_, W, kh, kw, dt, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(z0[:kh * kw], z1[:kh * kw])
+    assert torch.equal(o0, o1)
