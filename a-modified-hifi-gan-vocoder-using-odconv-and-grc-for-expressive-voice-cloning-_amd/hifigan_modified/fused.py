@@ -338,7 +338,15 @@ class GeneratorFused:
         dt = mel.dtype
         st = {}
         B = mel.shape[0]
+        # Mixed storage (ModifiedHiFiGANGenerator.set_mixed_precision; fp32-storage models only): the prologue, input_proj and the
+        # first `n_early` upsamplers run in `edt` (fp16) storage, the stream is cast to fp32 once, and everything behind runs with
+        # split operands.  tools/error_budget.py: fp16 through up1 costs 5.9e-4 of the 1e-3 waveform budget at 22 kHz.
+        mixed = getattr(g, "_mv_mixed", None)
+        n_early, edt = (mixed if (mixed is not None and dt == torch.float32) else (-1, dt))
+        sdt = lambda j: edt if j <= n_early else dt            # storage type of producer j (0 = input_proj, j = ups[j-1])
         mel = mel if mel.is_contiguous() else mel.contiguous()
+        if n_early >= 0:
+            mel = ops.cast(mel, edt)
         att = g.input_proj.kernel_attention[1]
         K0, C0 = att.weight.shape[0], att.weight.shape[1]
         # partial channel sums handed from each producer to its consumer (ODConv attention pooling, odconv.py:36-40,85): views of ONE
@@ -348,31 +356,32 @@ class GeneratorFused:
         prods = [self.inp] + self.ups[:-1]
         lens, T_ = [], mel.shape[2]
         for j, pr in enumerate(prods):
-            lens.append(pr.pool_floats(B, T_, dt, N.ACT_NONE if j == 0 else N.ACT_LRELU, has_film=(j == 0 and has_cond)))
+            lens.append(pr.pool_floats(B, T_, sdt(j), N.ACT_NONE if j == 0 else N.ACT_LRELU, has_film=(j == 0 and has_cond)))
             T_ = pr.out_len(T_)
         nflat = sum(B * n for n in lens)
         P = lambda t: None if t is None else c_void_p(t.data_ptr())
         fp = g.final_film.condition_projection
         F = g.final_film.feature_dim if has_cond else 0
         # one launch: attention of input_proj, the channels-last copy of the mel, the FiLM projection, the zero fill
+        d0 = sdt(0)
         flat = torch.empty(nflat, device=mel.device, dtype=torch.float32)
         alpha0 = torch.empty(B, K0, device=mel.device, dtype=torch.float32)
-        x = torch.empty(B, mel.shape[2], mel.shape[1], device=mel.device, dtype=dt)
-        film_proj = torch.empty(B, 2 * F, device=mel.device, dtype=dt) if has_cond else None
-        spk = None if speaker_emb is None else ops.cast(speaker_emb, dt).contiguous()
-        emo = None if emotion_emb is None else ops.cast(emotion_emb, dt).contiguous()
-        rc = N.lib().mv_gen_prologue(P(mel), P(cache.get(att.weight, dt)), P(cache.get(att.bias, dt)), P(spk), P(emo),
-                                     P(cache.get(fp.weight, dt)) if has_cond else None, P(cache.get(fp.bias, dt)) if has_cond else None,
+        x = torch.empty(B, mel.shape[2], mel.shape[1], device=mel.device, dtype=d0)
+        film_proj = torch.empty(B, 2 * F, device=mel.device, dtype=d0) if has_cond else None
+        spk = None if speaker_emb is None else ops.cast(speaker_emb, d0).contiguous()
+        emo = None if emotion_emb is None else ops.cast(emotion_emb, d0).contiguous()
+        rc = N.lib().mv_gen_prologue(P(mel), P(cache.get(att.weight, d0)), P(cache.get(att.bias, d0)), P(spk), P(emo),
+                                     P(cache.get(fp.weight, d0)) if has_cond else None, P(cache.get(fp.bias, d0)) if has_cond else None,
                                      P(alpha0), P(x), P(film_proj), None, 0, B, mel.shape[1], mel.shape[2], K0,
                                      0 if spk is None else spk.shape[1], 0 if emo is None else emo.shape[1], fp.in_features, 2 * F,
                                      ops._dt(mel), ops._stream())
         if rc == -3:    # MV_ERR_UNSUPPORTED: a long utterance does not fit one workgroup's LDS - separate launches
-            alpha0 = ops.odconv_attn(mel, cache.get(att.weight, dt).view(K0, C0), cache.get(att.bias, dt))
+            alpha0 = ops.odconv_attn(mel, cache.get(att.weight, d0).view(K0, C0), cache.get(att.bias, d0))
             x = ops.nct_to_ntc(mel)
             film_proj = None
             cond = g.final_film.condition(speaker_emb, emotion_emb)
             if cond is not None:
-                film_proj = ops.linear(ops.cast(cond, dt), cache.get(fp.weight, dt), cache.get(fp.bias, dt))
+                film_proj = ops.linear(ops.cast(cond, d0), cache.get(fp.weight, d0), cache.get(fp.bias, d0))
         else:
             N.check(rc, "mv_gen_prologue")
         cond = film_proj
@@ -383,12 +392,16 @@ class GeneratorFused:
         x = self.inp.forward_cl(x, cache, alpha=alpha0, film_proj=film_proj, film_F=F, pooled_out=views[0])
         if return_stages:
             st["film" if cond is not None else "input_proj"] = x
+        if n_early == 0:
+            x = ops.cast(x, dt)
         for i, u in enumerate(self.ups):
             nxt = views[i + 1] if i + 1 < len(self.ups) else None
             x = u.forward_cl(x, cache, pooled_in=views[i], pooled_out=nxt, act=N.ACT_LRELU,
                              slope=g.upsample_layers[i][1].negative_slope)
             if return_stages:
                 st[f"up{i}"] = x
+            if i + 1 == n_early:
+                x = ops.cast(x, dt)                            # the one storage-type change of the mixed mode
         # fp32 storage (split operands: matrix-pipe bound) runs the blocks as ONE chain - each block's GroupNorm(8,64) + residual is
         # applied by the next block's first pass, the last one by the output conv - 348 -> 281 us for the three blocks + output conv
         # at C2.  16-bit storage keeps the per-block kernels (the chain's extra stream transfer costs more than the MFMAs it saves:

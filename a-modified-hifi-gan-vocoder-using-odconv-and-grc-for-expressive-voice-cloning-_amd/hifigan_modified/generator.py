@@ -101,6 +101,27 @@ class ModifiedHiFiGANGenerator(nn.Module):
         for m in [self.input_proj] + [l[0] for l in self.upsample_layers]:
             yield from m.unused_parameters()
 
+    def set_mixed_precision(self, through="up1", dtype=torch.float16):
+        """Inference-only storage mix for an fp32-storage model (not in the reference): the stages up to and including `through`
+        ("input_proj", "up0", "up1", ...; None switches the mix off) run in `dtype` storage, everything behind - the last upsamplers,
+        the three MultiReceptiveFieldBlocks, the output conv - in fp32 storage with split bf16 MFMA operands.  The early stages feed
+        a 1e3x gain chain, but their rounding enters once; tools/error_budget.py puts fp16 through up1 at 5.9e-4 waveform rel-L2 on the
+        22 kHz generator (north_star: 1e-3) and above 1e-3 on the 48 kHz one - DESIGN.md section 5.  Returns self."""
+        if through is None:
+            mixed = None
+        else:
+            names = ["input_proj"] + [f"up{i}" for i in range(len(self.upsample_layers))]
+            if through not in names or dtype not in (torch.float16, torch.bfloat16):
+                raise ValueError(f"through must be one of {names} (or None), dtype fp16 / bf16")
+            mixed = (names.index(through), dtype)
+        object.__setattr__(self, "_mv_mixed", mixed)
+        return self
+
+    @property
+    def mixed_precision(self):
+        m = getattr(self, "_mv_mixed", None)
+        return None if m is None else ((["input_proj"] + [f"up{i}" for i in range(len(self.upsample_layers))])[m[0]], m[1])
+
     def forward(self, mel, speaker_emb=None, emotion_emb=None, return_stages=False, force_generic=False):
         if not force_generic and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
                                       ) and not (self.training and self.dropout > 0):

@@ -423,6 +423,36 @@ def test_full_c2_batch_properties(H):
             assert O.rel_l2(wave[i:i + 1].cpu(), ref) < 1e-3, i
 
 
+@pytest.mark.parametrize("through", ["up0", "up1"])
+def test_full_c2_batch_mixed_storage_meets_north_star(H, through):
+    """The mixed storage mode that bench.py headlines (ModifiedHiFiGANGenerator.set_mixed_precision: fp16 storage up to and including
+    `through`, fp32 storage with split MFMA operands behind it) at BASELINE configs[1]'s full size: four of the 32 clips against the
+    oracle within north_star's 1e-3 waveform rel-L2 (measured 4.6e-4 / 5.6e-4; tools/error_budget.py predicts 4.4e-4 / 5.9e-4), the
+    output is fp32, two runs agree bit for bit, and switching the mix off restores the all-fp32 result."""
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator()
+    sd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    gen = gen.cuda().train(False).set_mixed_precision(through)
+    assert gen.mixed_precision == (through, torch.float16)
+    torch.manual_seed(1)
+    mel, spk, emo = torch.randn(32, 80, 32), torch.randn(32, 192), torch.randn(32, 384)
+    with torch.no_grad():
+        wave = gen(mel.cuda(), spk.cuda(), emo.cuda())
+        again = gen(mel.cuda(), spk.cuda(), emo.cuda())
+        assert wave.shape == (32, 1, 8192) and wave.dtype == torch.float32 and torch.equal(wave, again)
+        errs = []
+        for i in (0, 7, 13, 31):
+            ref = O.generator_forward(mel[i:i + 1], sd, "", spk[i:i + 1], emo[i:i + 1])
+            errs.append(O.rel_l2(wave[i:i + 1].cpu(), ref))
+        print(f"[parity] mixed through {through}: waveform rel-L2 vs oracle {[f'{e:.2e}' for e in errs]}")
+        assert max(errs) < 1e-3, errs
+        full = gen.set_mixed_precision(None)(mel.cuda(), spk.cuda(), emo.cuda())
+        assert gen.mixed_precision is None
+        assert O.rel_l2(full[:1].cpu(), O.generator_forward(mel[:1], sd, "", spk[:1], emo[:1])) < 1e-4
+    with pytest.raises(ValueError):
+        gen.set_mixed_precision("mrf0")
+
+
 def test_full_c5_48k_batch_meets_north_star(H):
     """BASELINE configs[4]'s per-GPU share at its full size (128-mel, upsample [8,8,4,2], B=32 x 16 frames -> 8192 samples) in the
     parity-grade mode: two of the 32 clips against the oracle within north_star's 1e-3 (measured ~7e-5; this configuration saturates
