@@ -152,3 +152,20 @@ def test_torch_library_operators_are_registered_and_refuse_cpu_tensors():
     assert "Tensor(a!) p" in str(ns.fused_adamw_.default._schema)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ns.avg_pool1d(torch.randn(1, 1, 8), 2)
+
+
+def test_mixed_precision_switch_is_host_state_only():
+    """set_mixed_precision only records the split point; it validates its arguments and does not touch parameters."""
+    import hifigan_modified as H
+    g = H.ModifiedHiFiGANGenerator()
+    before = {k: v.clone() for k, v in g.state_dict().items()}
+    assert g.mixed_precision is None
+    assert g.set_mixed_precision("up1") is g and g.mixed_precision == ("up1", torch.float16)
+    assert g.set_mixed_precision("input_proj", torch.bfloat16).mixed_precision == ("input_proj", torch.bfloat16)
+    for bad in ("mrf0", "up9", "wave"):
+        with pytest.raises(ValueError):
+            g.set_mixed_precision(bad)
+    with pytest.raises(ValueError):
+        g.set_mixed_precision("up0", torch.float32)
+    assert g.set_mixed_precision(None).mixed_precision is None
+    assert all(torch.equal(v, before[k]) for k, v in g.state_dict().items()) and set(g.state_dict()) == set(before)
