@@ -180,6 +180,99 @@ __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restri
   }
 }
 
+// fp32 storage: the same fused ending with the channel contraction on the matrix pipe.  The VALU form above spends 23 k of its 44 k ticks
+// per workgroup in the dot products: a thread needs all ks x 64 weights, they arrive through ~14 serialised scalar loads per tap, and the
+// rows are read 11 times (176 ds_read_b128 per thread).  Here the taps are the MFMA rows, as in the discriminator head:
+//   z[tap][pos] = sum_c w[tap][c] * row[pos][c]   (A = the weights as a 16 x 64 operand, zero beyond ks; B = the staged rows, PRE-SPLIT
+//   into hi + lo bf16 planes when they are committed; 2 k-steps x 3 products per 16 positions, every row read ONCE),
+//   y[t] = bias + sum_tap z[tap][t + tap]          (the z tile replaces the rows in LDS after a barrier; 11 adds per output).
+template <int C>
+__global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* __restrict__ f, const float* __restrict__ x,
+                                                                   const float* __restrict__ ab, const float* __restrict__ w, float bias,
+                                                                   float* __restrict__ y, int Tn, int ks, int pad, int act) {
+  static_assert(C == 64, "two 32-channel k-steps");
+  using M = Mma<float>;
+  using V = M::V;
+  constexpr int TS = 256;
+  constexpr int PL = C * 2;                 // bytes of one bf16 plane of a row
+  constexpr int RS = 2 * PL + 16;           // hi plane, lo plane, pad
+  constexpr int CPR = C / 4;                // 4-channel columns per row (16 bytes of fp32 in, 8 + 8 bytes of bf16 out)
+  constexpr int UB = 9;
+  extern __shared__ __align__(16) char lds[];
+  const int b = blockIdx.y, t0 = blockIdx.x * TS, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int rows = TS + ks - 1, nblk = (rows + 15) / 16;
+  const float* xb = x + (size_t)b * Tn * C;
+  const float* fb = f + (size_t)b * Tn * C;
+  const int ch = tid % CPR;
+  float ra[4], rb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { ra[j] = ab[(size_t)b * 2 * C + ch * 4 + j]; rb[j] = ab[(size_t)b * 2 * C + C + ch * 4 + j]; }
+  // A operand: row = tap (lane & 15), k = 32 * kstep + 8 * (lane >> 4) + e  ->  w[tap][k]  (w is [ks][C] fp32)
+  V a[2];
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+    float wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wv[e] = col < ks ? w[col * C + k2 * 32 + 8 * g + e] : 0.f;
+    a[k2] = M::split(wv);
+  }
+  for (int r0 = tid / CPR; r0 < nblk * 16; r0 += (256 / CPR) * UB) {
+    f32x4 xv[UB], fv[UB];
+    bool ok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + u * (256 / CPR), t = t0 - pad + r;
+      ok[u] = r < rows && t >= 0 && t < Tn;
+      const size_t off = (size_t)(ok[u] ? t : 0) * C + ch * 4;
+      xv[u] = *reinterpret_cast<const f32x4*>(xb + off);
+      fv[u] = *reinterpret_cast<const f32x4*>(fb + off);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int r = r0 + u * (256 / CPR);
+      if (r < nblk * 16) {                  // rows beyond `rows` (the last block's tail) are zero operands
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = ok[u] ? ra[j] * fv[u][j] + rb[j] + xv[u][j] : 0.f;
+        u32x2 hi, lo;
+        M::split4(o, hi, lo);
+        *reinterpret_cast<u32x2*>(lds + (size_t)r * RS + ch * 8) = hi;
+        *reinterpret_cast<u32x2*>(lds + (size_t)r * RS + PL + ch * 8) = lo;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int MAXB = 5;                   // position blocks per wave: (256 + 15 + 15) / 16 = 17 blocks over 4 waves
+  f32x4 z[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pb = wid + 4 * i;
+    if (pb < nblk) {
+      const char* brow = lds + (size_t)(pb * 16 + col) * RS + g * 16;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) z[i] = M::mma(a[k2], M::load_bp(brow + k2 * 64, PL), z[i]);
+    }
+  }
+  __syncthreads();                          // every wave is done with the rows: the z tile takes their place
+  constexpr int ZS = TS + 32;               // floats per tap row of the z tile (>= 16 * nblk)
+  float* zt = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int pb = wid + 4 * i;
+    if (pb < nblk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[(4 * g + r) * ZS + pb * 16 + col] = z[i][r];
+    }
+  }
+  __syncthreads();
+  float acc = bias;
+  for (int j = 0; j < ks; ++j) acc += zt[j * ZS + tid + j];
+  const int t = t0 + tid;
+  if (t < Tn) y[(size_t)b * Tn + t] = apply_act(acc, act, 0.f);
+}
+
 }  // namespace mv
 
 using namespace mv;
@@ -189,6 +282,17 @@ int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const flo
                         int pad, int act, int dtype, hipStream_t stream) {
   if (C != 64 || 2 * pad != ks - 1) return MV_ERR_UNSUPPORTED;
   dim3 grid(cdiv(T_, 256), B);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("MV_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  if (dtype == MV_F32 && use_mfma && ks <= 16) {
+    const size_t rows16 = (size_t)((256 + ks - 1 + 15) / 16) * 16;
+    const size_t lds = rows16 * (2 * 64 * 2 + 16);       // >= the z tile (16 x 288 floats)
+    auto kern = conv_out_affine_mfma_kernel<64>;
+    static size_t lds_set_m = 0;
+    if (lds > lds_set_m) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set_m = lds; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)f, (const float*)x, ab, wt, bias, (float*)y, T_, ks, pad, act);
+    return MV_OK;
+  }
   MV_DISPATCH(dtype, {
     const size_t lds = (size_t)(256 + ks - 1) * (64 * Mma<T>::ES + 16);
     if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
