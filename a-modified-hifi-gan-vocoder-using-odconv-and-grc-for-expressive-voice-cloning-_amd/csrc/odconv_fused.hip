@@ -114,6 +114,51 @@ __device__ long long* od_dbg = nullptr;
 #else
 #define OD_TM() do {} while (0)
 #endif
+// logits z[s][k] = Wa[k] . mean[s] + ba[k] from the channel sums in `scratch` (sample s at scratch + s * sstride): a wave takes two
+// (sample, bank) pairs at a time and issues ALL their attention-weight loads before the first multiply - a `for (c = lane; c < Cin;
+// c += 64) acc += w[c] * m[c]` loop is one L2 round trip per 64 channels (8 in a row for the first upsampler's 512: 12 k of its 70 k
+// ticks went here, before anything else could start).
+template <typename T>
+__device__ __forceinline__ void od_logits(float* alds, const float* scratch, int sstride, int S, const OdP& p,
+                                          const T* __restrict__ att_w, const T* __restrict__ att_b) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int Cin = p.Cin, npair = S * p.K;
+  constexpr int U = 8;                                     // 64-channel slices per batch
+  for (int pr0 = wid * 2; pr0 < npair; pr0 += 8) {
+    float acc[2] = {0.f, 0.f};
+    for (int c0 = 0; c0 < Cin; c0 += 64 * U) {
+      float wv[2][U];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pr = pr0 + q < npair ? pr0 + q : npair - 1, kb = pr % p.K;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int cc = c0 + 64 * u + lane;
+          wv[q][u] = cc < Cin ? ld<T>(att_w + (long)kb * Cin + cc) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pr = pr0 + q < npair ? pr0 + q : npair - 1, s = pr / p.K;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int cc = c0 + 64 * u + lane;
+          if (cc < Cin) acc[q] += wv[q][u] * scratch[s * sstride + cc];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float v = wave_sum(acc[q]);
+      const int pr = pr0 + q;
+      if (lane == 0 && pr < npair) {
+        const int s = pr / p.K, kb = pr % p.K;
+        alds[s * OD_MAXK + kb] = v / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ attention prologue
 // alpha[s][:] = softmax_k( Wa . mean_t x + ba ) (odconv.py:36-40,85) for the S samples of a workgroup, from the PRODUCER's partial
 // channel sums (pooled_in: pool_n = slots x rows floats per sample, row % Cin = channel).  All 256 threads take part: thread t owns
@@ -125,7 +170,7 @@ template <typename T>
 __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scratch, int S, int b0, const OdP& p,
                                                        const float* __restrict__ pooled_in, const T* __restrict__ att_w,
                                                        const T* __restrict__ att_b) {
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x;
   const int Cin = p.Cin;
   const int npc = p.pool_n / Cin;                       // partials per channel
   if (Cin <= 256) {
@@ -150,13 +195,7 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
       scratch[(s * G) * Cin + cc] = a;
     }
     __syncthreads();
-    for (int pr = wid; pr < S * p.K; pr += 4) {           // logits: wave per (sample, bank)
-      const int s = pr / p.K, kb = pr % p.K;
-      float acc = 0.f;
-      for (int cc = lane; cc < Cin; cc += 64) acc += ld<T>(att_w + (long)kb * Cin + cc) * scratch[(s * G) * Cin + cc];
-      acc = wave_sum(acc);
-      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
-    }
+    od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b);
   } else {
     // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel; a thread owns channels tid, tid + 256, ...
     for (int s = 0; s < S; ++s)
@@ -164,18 +203,17 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
         float a = 0.f;
         if (b0 + s < p.B) {
           const float* src = pooled_in + (long)(b0 + s) * p.pool_n + c;
-          for (int j = 0; j < npc; ++j) a += src[(long)j * Cin];
+          int j = 0;
+          for (; j + 3 < npc; j += 4) {                  // four independent loads in flight, added in index order
+            const float v0 = src[(long)j * Cin], v1 = src[(long)(j + 1) * Cin], v2 = src[(long)(j + 2) * Cin], v3 = src[(long)(j + 3) * Cin];
+            a += v0; a += v1; a += v2; a += v3;
+          }
+          for (; j < npc; ++j) a += src[(long)j * Cin];
         }
         scratch[s * Cin + c] = a;                        // needs S * Cin floats of scratch
       }
     __syncthreads();
-    for (int pr = wid; pr < S * p.K; pr += 4) {
-      const int s = pr / p.K, kb = pr % p.K;
-      float acc = 0.f;
-      for (int cc = lane; cc < Cin; cc += 64) acc += ld<T>(att_w + (long)kb * Cin + cc) * scratch[s * Cin + cc];
-      acc = wave_sum(acc);
-      if (lane == 0) alds[s * OD_MAXK + kb] = acc / (float)p.Tin + (att_b ? ld<T>(att_b + kb) : 0.f);
-    }
+    od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b);
   }
   __syncthreads();
   if (tid < S) {
