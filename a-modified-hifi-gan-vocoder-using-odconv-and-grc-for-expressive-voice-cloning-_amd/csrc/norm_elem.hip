@@ -103,9 +103,9 @@ __device__ long long* pro_dbg = nullptr;
 #else
 #define PRO_TM() do {} while (0)
 #endif
-template <typename T>
-__global__ __launch_bounds__(1024) void gen_prologue_kernel(const T* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
-                                                           const T* __restrict__ spk, const T* __restrict__ emo, const T* __restrict__ film_w,
+template <typename T, typename TI>
+__global__ __launch_bounds__(1024) void gen_prologue_kernel(const TI* __restrict__ mel, const T* __restrict__ att_w, const T* __restrict__ att_b,
+                                                           const TI* __restrict__ spk, const TI* __restrict__ emo, const T* __restrict__ film_w,
                                                            const T* __restrict__ film_b, float* __restrict__ alpha, T* __restrict__ x_cl,
                                                            T* __restrict__ film_proj, float* __restrict__ zero_buf, long zero_n, int B,
                                                            int C, int Tn, int K, int ds, int de, int cond_dim, int F2) {
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(1024) void gen_prologue_kernel(const T* __restrict_
       const int s = e / cond_dim, i = e - s * cond_dim, b = s0 + s;
       float v = 0.f;
       if (b < B) {
-        if (i < ds) v = ld<T>(spk + (long)b * ds + i);
-        else if (i < ds + de) v = ld<T>(emo + (long)b * de + (i - ds));
+        if (i < ds) v = ld<TI>(spk + (long)b * ds + i);
+        else if (i < ds + de) v = ld<TI>(emo + (long)b * de + (i - ds));
       }
       cl[e] = v;
     }
@@ -176,19 +176,19 @@ __global__ __launch_bounds__(1024) void gen_prologue_kernel(const T* __restrict_
   float* xs = sm;                        // [C][TP]
   float* psum = xs + C * TP;             // [P][C] slice sums
   float* mean = psum + P * C;            // [C]
-  const T* xb = mel + (long)b * C * Tn;
+  const TI* xb = mel + (long)b * C * Tn;
   // every global load is issued before the first barrier: the mel and (wave 0) the attention weights, into registers
   if (C * Tn <= 4 * nt) {
     float mv4[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mv4[u] = tid + u * nt < C * Tn ? ld<T>(xb + tid + u * nt) : 0.f;
+    for (int u = 0; u < 4; ++u) mv4[u] = tid + u * nt < C * Tn ? ld<TI>(xb + tid + u * nt) : 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = tid + u * nt, c = i / Tn;
       if (i < C * Tn) xs[c * TP + (i - c * Tn)] = mv4[u];
     }
   } else {
-    for (int i = tid; i < C * Tn; i += nt) { const int c = i / Tn; xs[c * TP + (i - c * Tn)] = ld<T>(xb + i); }
+    for (int i = tid; i < C * Tn; i += nt) { const int c = i / Tn; xs[c * TP + (i - c * Tn)] = ld<TI>(xb + i); }
   }
   constexpr int AK = 4, AWN = 4;         // attention weights wave 0 keeps: banks < AK, channels lane + 64 i, i < AWN
   const bool areg = K <= AK && C <= 64 * AWN;
@@ -600,9 +600,22 @@ extern "C" int mv_odconv_attn_fwd(const void* x, const void* w, const void* bias
   return MV_OK;
 }
 
+extern "C" int mv_gen_prologue_in(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo,
+                                  const void* film_w, const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf,
+                                  long zero_n, int B, int C, int T_, int K, int ds, int de, int cond_dim, int F2, int in_dtype, int dtype,
+                                  void* stream);
 extern "C" int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo,
                                const void* film_w, const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf,
                                long zero_n, int B, int C, int T_, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream) {
+  return mv_gen_prologue_in(mel, att_w, att_b, spk, emo, film_w, film_b, alpha, x_cl, film_proj, zero_buf, zero_n, B, C, T_, K, ds, de,
+                            cond_dim, F2, dtype, dtype, stream);
+}
+
+extern "C" int mv_gen_prologue_in(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo,
+                                  const void* film_w, const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf,
+                                  long zero_n, int B, int C, int T_, int K, int ds, int de, int cond_dim, int F2, int in_dtype, int dtype,
+                                  void* stream) {
+  if (in_dtype != dtype && in_dtype != MV_F32) return MV_ERR_DTYPE;      // inputs (mel, spk, emo): the storage type, or fp32
   MV_CHECK_ARG(mel && att_w && alpha && x_cl && B > 0 && C > 0 && T_ > 0 && K > 0 && K <= 64 && ds >= 0 && de >= 0 && zero_n >= 0);
   MV_CHECK_ARG((ds == 0 || spk) && (de == 0 || emo) && (!film_proj || (film_w && cond_dim > 0 && F2 > 0)) && (zero_n == 0 || zero_buf));
   constexpr int NT = 1024, NW = NT / 64;
@@ -617,10 +630,16 @@ extern "C" int mv_gen_prologue(const void* mel, const void* att_w, const void* a
   static int calls = 0;
   if (!dbg) { hipMalloc(&dbg, 1024 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(pro_dbg), &dbg, sizeof(dbg)); }
 #endif
-  MV_DISPATCH(dtype, hipLaunchKernelGGL(gen_prologue_kernel<T>, dim3(B + n_film), dim3(NT), lds, (hipStream_t)stream, (const T*)mel,
-                                        (const T*)att_w, (const T*)att_b, (const T*)spk, (const T*)emo, (const T*)film_w,
-                                        (const T*)film_b, alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, B, C, T_, K, ds, de,
-                                        film_proj ? cond_dim : 0, F2));
+  MV_DISPATCH(dtype, {
+    if (in_dtype == dtype)
+      hipLaunchKernelGGL((gen_prologue_kernel<T, T>), dim3(B + n_film), dim3(NT), lds, (hipStream_t)stream, (const T*)mel,
+                         (const T*)att_w, (const T*)att_b, (const T*)spk, (const T*)emo, (const T*)film_w, (const T*)film_b, alpha,
+                         (T*)x_cl, (T*)film_proj, zero_buf, zero_n, B, C, T_, K, ds, de, film_proj ? cond_dim : 0, F2);
+    else
+      hipLaunchKernelGGL((gen_prologue_kernel<T, float>), dim3(B + n_film), dim3(NT), lds, (hipStream_t)stream, (const float*)mel,
+                         (const T*)att_w, (const T*)att_b, (const float*)spk, (const float*)emo, (const T*)film_w, (const T*)film_b,
+                         alpha, (T*)x_cl, (T*)film_proj, zero_buf, zero_n, B, C, T_, K, ds, de, film_proj ? cond_dim : 0, F2);
+  });
 #ifdef MV_PRO_TIMING
   if (++calls == 2 && B <= 1024) {
     hipStreamSynchronize((hipStream_t)stream);

@@ -36,6 +36,7 @@ struct OdP {
   int nrows;      // LDS rows per sample tile
   int film_F;
   int pool_n;     // floats per sample in pooled_in: slots * rows partial sums of the producing launch (Cin = dense sums)
+  int in_f16;     // fp32 launch whose INPUT x is fp16 (mixed storage: the first fp32 stage reads the fp16 stream; multi-tile kernel only)
 };
 
 template <typename T> struct WLoad;   // this lane's 8 packed weights -> fp32
@@ -527,8 +528,8 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
 // wave's rows stay in registers as ready A operands).  The x tile of the NEXT step travels global -> registers under the MFMAs of
 // the current one (unconditional, row-clamped loads) and is committed to LDS after the current tile's stores, so no global-load
 // latency sits on the per-tile path.  16-bit storage, LeakyReLU / none, no FiLM.
-template <typename T, int MW, int NB, int CIN, int KB>
-__global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
+template <typename T, int MW, int NB, int CIN, int KB, typename TI = T>
+__global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
                                                            const float* __restrict__ alpha_in, const float* __restrict__ pooled_in,
                                                            const T* __restrict__ att_w, const T* __restrict__ att_b, T* __restrict__ y,
                                                            float* __restrict__ pooled_out, OdP p, int TL) {
@@ -536,7 +537,9 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
   using V = typename M::V;
   using WL = WLoad<T>;
   // fp32 storage: x tiles PRE-SPLIT into hi / lo bf16 planes at commit (split operands, mfma.h); ES = element size in HBM, LES in LDS
-  constexpr int ES = M::ES, LES = 2, NTAPS = 2, CPR = CIN * ES / 16, CPC = CIN / 8, KST = NTAPS * CIN / 32;
+  // TI: element type of x in HBM (T, or fp16 feeding an fp32 launch: widened and split as the tile is committed)
+  constexpr int ES = M::ES, LES = 2, NTAPS = 2, ESI = sizeof(TI), CPR = CIN * ESI / 16, CPC = CIN / 8, KST = NTAPS * CIN / 32;
+  static_assert(ESI == ES || (ES == 4 && ESI == 2), "input type: the storage type, or fp16 into fp32");
   constexpr bool SPLIT = (ES == 4);
   constexpr int PLANE = CIN * LES;
   constexpr int NROWS = NB * 16 + NTAPS - 1, PER = NROWS * CPR, XP = (PER + 255) / 256;
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
       int i = tid + j * 256; if (i >= PER) i = PER - 1;
       const int r = i / CPR, ch = i % CPR;
       int tin = q0 + p.shift_lo + r; tin = tin < 0 ? 0 : (tin >= p.Tin ? p.Tin - 1 : tin);
-      xreg[j] = *reinterpret_cast<const uint4*>(xb + ((long)tin * CIN) * ES + ch * 16);
+      xreg[j] = *reinterpret_cast<const uint4*>(xb + ((long)tin * CIN) * ESI + ch * 16);
     }
   };
   auto xcommit = [&](int q0) {
@@ -573,7 +576,16 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
       if (i < PER) {
         const int r = i / CPR, ch = i % CPR, tin = q0 + p.shift_lo + r;
         const uint4 v = (tin >= 0 && tin < p.Tin) ? xreg[j] : make_uint4(0, 0, 0, 0);
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && ESI == 2) {                    // 8 fp16 channels -> 8 hi + 8 lo bf16
+          alignas(16) f16 hv[8];
+          *reinterpret_cast<uint4*>(hv) = v;
+          const f32x4 f0 = {(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]}, f1 = {(float)hv[4], (float)hv[5], (float)hv[6], (float)hv[7]};
+          u32x2 h0, l0, h1, l1;
+          Mma<float>::split4(f0, h0, l0);
+          Mma<float>::split4(f1, h1, l1);
+          *reinterpret_cast<u32x4*>(xl + r * RS + ch * 16) = u32x4{h0[0], h0[1], h1[0], h1[1]};
+          *reinterpret_cast<u32x4*>(xl + r * RS + PLANE + ch * 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};
+        } else if constexpr (SPLIT) {
           u32x2 hi, lo;
           Mma<float>::split4(__builtin_bit_cast(f32x4, v), hi, lo);
           *reinterpret_cast<u32x2*>(xl + r * RS + ch * 8) = hi;
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const T* __restrict__
   }
 }
 
-template <typename T, int MW, int NB, int CIN>
+template <typename T, int MW, int NB, int CIN, typename TI = T>
 static int od_mt_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
                         const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream, int* slots_out) {
   constexpr int ES = Mma<T>::ES;
@@ -737,7 +749,7 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   const size_t obytes = (size_t)NB * 16 * (4 * MW * 16 * ES + 16);
   const size_t lds = sizeof(float) * (OD_MAXK + 4 * MW * 16) + (xbytes > obytes ? xbytes : obytes);
   if (lds > 80 * 1024) return MV_ERR_UNSUPPORTED;
-  auto kern = odconv_cl_mt_kernel<T, MW, NB, CIN, 4>;
+  auto kern = odconv_cl_mt_kernel<T, MW, NB, CIN, 4, TI>;
   static size_t lds_set = 0;
   if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
   const int ntl = cdiv(p.nq, NB * 16);
@@ -751,7 +763,7 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   dim3 grid(cdiv(ntl, TL), gy, p.B);
   if (grid.y > 65535 || grid.z > 65535) return MV_ERR_UNSUPPORTED;
   if (slots_out) { *slots_out = (int)grid.x; return MV_OK; }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha,
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const TI*)x, (const T*)wp, (const T*)bias, alpha,
                      pooled_in, (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p, TL);
   return MV_OK;
 }
@@ -1183,6 +1195,7 @@ static bool od_make(OdP* p, int B, int Cin, int Tin, int Cout, int Tout, int ks,
   p->ksteps = cdiv(p->nchunks, 4);
   p->nrows = 0;
   p->pool_n = Cin;
+  p->in_f16 = 0;
   return true;
 }
 
@@ -1240,6 +1253,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
     if (K <= 4 && p.ksteps <= 8 && !force_pf) rc = od_launch<T, S_, MW_, NB_, false, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); \
     else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); \
     else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); } while (0)
+  if (p.in_f16 && (dtype != MV_F32 || ntiles <= 3 || wbytes > (1 << 20))) return MV_ERR_UNSUPPORTED;   // (only the multi-tile kernel below)
   MV_DISPATCH(dtype, {
     if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler)
       rc = MV_ERR_UNSUPPORTED;
@@ -1288,11 +1302,15 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
             if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
             else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
           } else {   // fp32 (operands are hi/lo register pairs): 64-column tiles; at 128 channels ONE M-tile per wave (two cost a wave per SIMD: 60 us)
-            if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+            if (p.in_f16) {
+              if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+              else rc = od_mt_launch<T, 1, 4, 128, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+            } else if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
             else rc = od_mt_launch<T, 1, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);   // ups2 49 -> 38 us
           }
         }
       }
+      if (p.in_f16) return rc;                               // only the multi-tile kernel widens its input
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 8);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     }
@@ -1301,11 +1319,11 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
   return rc;
 }
 
-extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha,
-                                const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
-                                const void* film_proj, int film_F, void* y, float* pooled_out, int B, int Cin, int Tin,
-                                int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
-                                float slope, int dtype, void* stream) {
+static int odconv_cl_fwd_impl(const void* x, const void* packed, const void* bias, const float* alpha,
+                              const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
+                              const void* film_proj, int film_F, void* y, float* pooled_out, int B, int Cin, int Tin,
+                              int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
+                              float slope, int dtype, void* stream, int in_f16) {
   MV_CHECK_ARG(x && packed && y && (alpha || (pooled_in && att_w && pooled_in_count > 0 && pooled_in_count % Cin == 0)));
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0);
   MV_CHECK_ARG(((uintptr_t)pooled_out & 15) == 0);
@@ -1313,11 +1331,29 @@ extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* b
   if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, film_proj ? film_F : 0))
     return MV_ERR_UNSUPPORTED;
   if (pooled_in) p.pool_n = pooled_in_count;
+  p.in_f16 = in_f16;
   const int rc = od_dispatch(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, dtype,
                              (hipStream_t)stream, nullptr);
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   return MV_OK;
+}
+
+extern "C" int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const float* alpha,
+                                const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
+                                const void* film_proj, int film_F, void* y, float* pooled_out, int B, int Cin, int Tin,
+                                int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
+                                float slope, int dtype, void* stream) {
+  return odconv_cl_fwd_impl(x, packed, bias, alpha, pooled_in, pooled_in_count, att_w, att_b, film_proj, film_F, y, pooled_out, B, Cin,
+                            Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, dtype, stream, 0);
+}
+
+extern "C" int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, const void* bias, const float* alpha,
+                                     const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
+                                     void* y, float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride,
+                                     int pad, int dil, int transposed, int K, int act, float slope, void* stream) {
+  return odconv_cl_fwd_impl(x_f16, packed, bias, alpha, pooled_in, pooled_in_count, att_w, att_b, nullptr, 0, y, pooled_out, B, Cin,
+                            Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, MV_F32, stream, 1);
 }
 
 extern "C" size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,

@@ -282,16 +282,30 @@ class OdconvFused:
         return n
 
     def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
-                   act=N.ACT_NONE, slope=0.1):
-        """pooled_in / pooled_out: fp32 [B, n] partial channel sums (n = the producer's / this layer's pool_floats)."""
+                   act=N.ACT_NONE, slope=0.1, storage=None):
+        """pooled_in / pooled_out: fp32 [B, n] partial channel sums (n = the producer's / this layer's pool_floats).
+        storage = torch.float32 with an fp16 x_cl: the first fp32 stage of the mixed mode - the kernel widens its input while
+        staging it (mv_odconv_cl_fwd_in16) where that variant exists, else x_cl is cast first."""
         m = self.mod
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         B, Tin, C = x_cl.shape
         assert C == cin and x_cl.is_contiguous()
         Tout = self.out_len(Tin)
-        y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=x_cl.dtype)
         att = m.kernel_attention[1]
         P = lambda t: None if t is None else c_void_p(t.data_ptr())
+        if storage is not None and storage != x_cl.dtype:
+            if storage == torch.float32 and x_cl.dtype == torch.float16 and film_proj is None:
+                y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=storage)
+                rc = N.lib().mv_odconv_cl_fwd_in16(P(x_cl), P(self.packed(storage, x_cl.device)), P(cache.get(m.bias, storage)), P(alpha),
+                                                   P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
+                                                   P(cache.get(att.weight, storage)), P(cache.get(att.bias, storage)), P(y), P(pooled_out),
+                                                   B, cin, Tin, cout, Tout, ks, stride, pad, dil, int(tr), K, int(act), float(slope),
+                                                   ops._stream())
+                if rc != -3:                                   # MV_ERR_UNSUPPORTED: no input-widening variant for this geometry
+                    N.check(rc, "mv_odconv_cl_fwd_in16")
+                    return y
+            x_cl = ops.cast(x_cl, storage)
+        y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=x_cl.dtype)
         N.call("mv_odconv_cl_fwd", P(x_cl), P(self.packed(x_cl.dtype, x_cl.device)), P(cache.get(m.bias, x_cl.dtype)),
                P(alpha), P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
                P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)),
@@ -345,8 +359,6 @@ class GeneratorFused:
         n_early, edt = (mixed if (mixed is not None and dt == torch.float32) else (-1, dt))
         sdt = lambda j: edt if j <= n_early else dt            # storage type of producer j (0 = input_proj, j = ups[j-1])
         mel = mel if mel.is_contiguous() else mel.contiguous()
-        if n_early >= 0:
-            mel = ops.cast(mel, edt)
         att = g.input_proj.kernel_attention[1]
         K0, C0 = att.weight.shape[0], att.weight.shape[1]
         # partial channel sums handed from each producer to its consumer (ODConv attention pooling, odconv.py:36-40,85): views of ONE
@@ -368,14 +380,17 @@ class GeneratorFused:
         alpha0 = torch.empty(B, K0, device=mel.device, dtype=torch.float32)
         x = torch.empty(B, mel.shape[2], mel.shape[1], device=mel.device, dtype=d0)
         film_proj = torch.empty(B, 2 * F, device=mel.device, dtype=d0) if has_cond else None
-        spk = None if speaker_emb is None else ops.cast(speaker_emb, d0).contiguous()
-        emo = None if emotion_emb is None else ops.cast(emotion_emb, d0).contiguous()
-        rc = N.lib().mv_gen_prologue(P(mel), P(cache.get(att.weight, d0)), P(cache.get(att.bias, d0)), P(spk), P(emo),
-                                     P(cache.get(fp.weight, d0)) if has_cond else None, P(cache.get(fp.bias, d0)) if has_cond else None,
-                                     P(alpha0), P(x), P(film_proj), None, 0, B, mel.shape[1], mel.shape[2], K0,
-                                     0 if spk is None else spk.shape[1], 0 if emo is None else emo.shape[1], fp.in_features, 2 * F,
-                                     ops._dt(mel), ops._stream())
+        # the prologue reads mel / spk / emo in the caller's type (mixed mode: fp32 inputs, fp16 outputs - no cast launches)
+        idt = mel.dtype
+        spk = None if speaker_emb is None else ops.cast(speaker_emb, idt).contiguous()
+        emo = None if emotion_emb is None else ops.cast(emotion_emb, idt).contiguous()
+        rc = N.lib().mv_gen_prologue_in(P(mel), P(cache.get(att.weight, d0)), P(cache.get(att.bias, d0)), P(spk), P(emo),
+                                        P(cache.get(fp.weight, d0)) if has_cond else None, P(cache.get(fp.bias, d0)) if has_cond else None,
+                                        P(alpha0), P(x), P(film_proj), None, 0, B, mel.shape[1], mel.shape[2], K0,
+                                        0 if spk is None else spk.shape[1], 0 if emo is None else emo.shape[1], fp.in_features, 2 * F,
+                                        ops._DT[idt], ops._DT[d0], ops._stream())
         if rc == -3:    # MV_ERR_UNSUPPORTED: a long utterance does not fit one workgroup's LDS - separate launches
+            mel = ops.cast(mel, d0)
             alpha0 = ops.odconv_attn(mel, cache.get(att.weight, d0).view(K0, C0), cache.get(att.bias, d0))
             x = ops.nct_to_ntc(mel)
             film_proj = None
@@ -392,16 +407,15 @@ class GeneratorFused:
         x = self.inp.forward_cl(x, cache, alpha=alpha0, film_proj=film_proj, film_F=F, pooled_out=views[0])
         if return_stages:
             st["film" if cond is not None else "input_proj"] = x
-        if n_early == 0:
-            x = ops.cast(x, dt)
         for i, u in enumerate(self.ups):
             nxt = views[i + 1] if i + 1 < len(self.ups) else None
+            # (mixed mode: the first fp32-storage upsampler takes the fp16 stream as it is - the one storage-type change)
             x = u.forward_cl(x, cache, pooled_in=views[i], pooled_out=nxt, act=N.ACT_LRELU,
-                             slope=g.upsample_layers[i][1].negative_slope)
+                             slope=g.upsample_layers[i][1].negative_slope, storage=sdt(i + 1))
             if return_stages:
                 st[f"up{i}"] = x
-            if i + 1 == n_early:
-                x = ops.cast(x, dt)                            # the one storage-type change of the mixed mode
+        if x.dtype != dt:
+            x = ops.cast(x, dt)                                # every upsampler ran in the early type
         # fp32 storage (split operands: matrix-pipe bound) runs the blocks as ONE chain - each block's GroupNorm(8,64) + residual is
         # applied by the next block's first pass, the last one by the output conv - 348 -> 281 us for the three blocks + output conv
         # at C2.  16-bit storage keeps the per-block kernels (the chain's extra stream transfer costs more than the MFMAs it saves:

@@ -211,6 +211,14 @@ int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const 
                      int pooled_in_count, const void* att_w, const void* att_b, const void* film_proj, int film_F, void* y,
                      float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad,
                      int dil, int transposed, int K, int act, float slope, int dtype, void* stream);
+/* mv_odconv_cl_fwd in fp32 storage (packed weights, bias, attention head and y are fp32) whose INPUT x is fp16: the first fp32
+ * stage of the mixed storage mode reads the fp16 stream directly (widened and split while its tiles are staged) instead of a cast
+ * launch.  Only the geometries of the multi-tile kernel (ODConvTranspose1d, ks = 2 * stride, 64 / 128 input channels, small banks);
+ * MV_ERR_UNSUPPORTED otherwise - cast and call mv_odconv_cl_fwd. */
+int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
+                          int pooled_in_count, const void* att_w, const void* att_b, void* y, float* pooled_out, int B, int Cin,
+                          int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
+                          float slope, void* stream);
 /* floats PER SAMPLE that the launch above writes to pooled_out (0 = unsupported geometry): slots x GEMM rows, where the slot
  * count follows the kernel variant the dispatcher picks for this geometry. */
 size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
@@ -222,6 +230,11 @@ size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int
 int mv_gen_prologue(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo, const void* film_w,
                     const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf, long zero_n, int B, int C,
                     int T, int K, int ds, int de, int cond_dim, int F2, int dtype, void* stream);
+/* the same with the INPUTS (mel, spk, emo) in in_dtype = dtype or fp32: a 16-bit-storage front of an fp32 model reads the caller's
+ * fp32 tensors directly (the mixed storage mode) instead of three cast launches. */
+int mv_gen_prologue_in(const void* mel, const void* att_w, const void* att_b, const void* spk, const void* emo, const void* film_w,
+                       const void* film_b, float* alpha, void* x_cl, void* film_proj, float* zero_buf, long zero_n, int B, int C,
+                       int T, int K, int ds, int de, int cond_dim, int F2, int in_dtype, int dtype, void* stream);
 
 /* Output projection, channels-last in, waveform out.   replaces SURVEY.md §A item 4: nn.Conv1d(C,1,ks,padding=ks/2) + torch.tanh
  *   x [B][T][C] -> y [B][1][T].  wt = mv_conv_out_pack(weight [1,C,ks]) (fp32 [ks][C]).  C must be 64, ks odd. */
