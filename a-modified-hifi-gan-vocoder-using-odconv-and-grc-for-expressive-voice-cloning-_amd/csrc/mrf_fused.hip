@@ -248,6 +248,11 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   constexpr int PLANE = MRF_C * LES;                  // byte offset of the lo plane inside a row (SPLIT)
   constexpr int RS = (SPLIT ? 2 * PLANE : MRF_C * ES) + 32;   // padded LDS row stride: conflict-free ds_read_b128 operand reads
   constexpr int WBYTES = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
+  // fp32 statistics-of-v passes (1, 4) use the branch-conv fragments only: staging just those (64 of the 96 KB) leaves room for
+  // a 256-step shared tile, i.e. NTW = 2 - every weight fragment read from LDS then feeds two column tiles (LDS reads per MFMA
+  // 0.83 -> 0.5; the passes are bound by the LDS pipe: 150 operand reads for 144 MFMAs per wave and 16-step tile)
+  constexpr bool CONV_ONLY = (ES == 4) && STATS_V;
+  constexpr int WLB = CONV_ONLY ? MRF_CONV_FRAGS * FS : WBYTES;       // bytes of weights resident in LDS
   constexpr int TW = NTW * 16;                        // time steps per wave and iteration
   constexpr int CH = MRF_C * ES / 16;                 // 16-byte chunks per row
   // 16-bit storage: every wave stages a PRIVATE tile (TW + 2 halo rows; no workgroup barrier on the data path).  fp32 storage
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
   extern __shared__ __align__(16) char lds[];
   char* wl = lds;                                           // packed weights
-  float* tab = reinterpret_cast<float*>(lds + WBYTES);      // 7 x 64 floats
+  float* tab = reinterpret_cast<float*>(lds + WLB);         // 7 x 64 floats
   float* st5 = tab + MRF_TAB_FLOATS;                        // [16][2] mean, rstd
   float* st8 = st5 + 32;                                    // [8][2]
   float* red = st8 + 16;                                    // [NWAVES][16][2] partial sums
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 
   // ---- stage packed weights + tables (whole workgroup, once): all global loads of a thread in flight together
   {
-    constexpr int N16 = (WBYTES + MRF_TAB_FLOATS * 4) / 16;
+    constexpr int N16 = (WLB + MRF_TAB_FLOATS * 4) / 16;      // resident fragments, then the tables (behind ALL fragments in `packed`)
     constexpr int PER = (N16 + NWAVES * 64 - 1) / (NWAVES * 64);
     const u32x4* src = reinterpret_cast<const u32x4*>(packed);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
@@ -357,8 +362,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     if constexpr (NEED_W) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        const int idx = tid + i * NWAVES * 64;
-        wv[i] = src[idx < N16 ? idx : N16 - 1];
+        int idx = tid + i * NWAVES * 64;
+        idx = idx < N16 ? idx : N16 - 1;
+        wv[i] = src[idx < WLB / 16 ? idx : idx + (WBYTES - WLB) / 16];
       }
     }
     // GroupNorm statistics from the previous passes' partial sums: one partial per thread, then a fixed-order sum in LDS
@@ -835,17 +841,33 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
   float* part5 = reinterpret_cast<float*>(ws + 3 * act);
   float* part8 = part5 + (size_t)B * nwg * 32;
   const dim3 grid(nwg, B);
+  // fp32: the statistics-of-v passes (1, 4) keep only the branch-conv fragments in LDS and run 32-step wave tiles (see the kernel);
+  // same workgroup count, half the iterations, so the partial-sum buffers line up with the 16-step passes
+  constexpr bool WIDE_OK = (M::ES == 4) && NTW == 1;
+  const size_t lds_wide = (size_t)MRF_CONV_FRAGS * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 + (size_t)NWAVES * 32 * 4 +
+                          ((size_t)NWAVES * 2 * 16 + 2 * hmax) * RS;
+  static int wide_env = -1;
+  if (wide_env < 0) { const char* e = getenv("MV_MRF_WIDE_STATS"); wide_env = e ? atoi(e) : 1; }   // bit 0: pass 1, bit 1: pass A
+  const bool wide = WIDE_OK && wide_env && nit >= 2 && nit % 2 == 0 && lds_wide <= 160 * 1024 && Tn % (NWAVES * 32) == 0;
   const T* xi = (const T*)x;                         // x_i: the input of block i
   for (int i = 0; i < nblocks; ++i) {
     const bool stdm = mrf_meta_is_std(metas[i]);
     const char* pk = (const char*)packed[i];
     if (i == 0) {
-      mrf_chain_pass<T, NWAVES, NTW, 1>(stdm, grid, lds, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr, nullptr, Tn, nwg,
-                                        nit, eps, nullptr, nullptr);
+      if (wide && (wide_env & 1))
+        mrf_chain_pass<T, NWAVES, (WIDE_OK ? 2 : NTW), 1>(stdm, grid, lds_wide, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr,
+                                                          nullptr, Tn, nwg, nit / 2, eps, nullptr, nullptr);
+      else
+        mrf_chain_pass<T, NWAVES, NTW, 1>(stdm, grid, lds, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr, nullptr, Tn, nwg,
+                                          nit, eps, nullptr, nullptr);
     } else {
       T* xn = xbuf[i & 1];                           // pass A: x_i = GN8_{i-1}(f_{i-1}) + x_{i-1}, written once; statistics of v_i
-      mrf_chain_pass<T, NWAVES, NTW, 4>(stdm, grid, lds, stream, xi, xn, pk, metas[i], nullptr, part5, part8, nullptr, Tn, nwg, nit, eps,
-                                        fbuf, (const char*)packed[i - 1]);
+      if (wide && (wide_env & 2))      // (pass A at 32-step tiles needs 256 VGPRs + spills: 50 vs 43 us - off by default)
+        mrf_chain_pass<T, NWAVES, (WIDE_OK ? 2 : NTW), 4>(stdm, grid, lds_wide, stream, xi, xn, pk, metas[i], nullptr, part5, part8, nullptr,
+                                                          Tn, nwg, nit / 2, eps, fbuf, (const char*)packed[i - 1]);
+      else
+        mrf_chain_pass<T, NWAVES, NTW, 4>(stdm, grid, lds, stream, xi, xn, pk, metas[i], nullptr, part5, part8, nullptr, Tn, nwg, nit, eps,
+                                          fbuf, (const char*)packed[i - 1]);
       xi = xn;
     }
     // pass B: stages 1-3 once, f_i -> fbuf, statistics of f_i
