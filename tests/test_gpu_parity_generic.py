@@ -542,3 +542,56 @@ def test_output_conv_packed_images_vs_fp64(H, dtype, B, T, ks):
     assert O.rel_l2(y.double().cpu(), ref.cpu()) < tol
     assert N.lib().mv_conv_out_act_packed_cl(P(x), P(packed), ctypes.c_float(bias), P(y), B, T, 32, ks, ks // 2, N.ACT_TANH, ops._dt(x),
                                              ops._stream()) == -3        # only the 64-channel stream is built
+
+
+def test_mixed_mode_entry_points_match_their_cast_forms(H):
+    """The two entry points that let the mixed storage mode change type without cast launches, against cast + the plain entry point:
+    mv_odconv_cl_fwd_in16 (fp32 ODConvTranspose1d fed an fp16 stream: widening is exact, so the result is bit-identical) and
+    mv_gen_prologue_in (fp16 prologue fed fp32 mel / embeddings: x_cl and the FiLM projection see the same rounded inputs; the
+    attention weights are formed from the unrounded mel, i.e. agree to fp16 rounding of the mean)."""
+    from ctypes import c_void_p
+    from hifigan_modified import _native as N, ops, functional as Fn
+    from hifigan_modified.fused import generator_fused_for
+    torch.manual_seed(0)
+    gen = H.ModifiedHiFiGANGenerator().cuda().train(False)
+    fz = generator_fused_for(gen)
+    P = lambda t: None if t is None else c_void_p(t.data_ptr())
+    B = 4
+    # --- the third upsampler (128 -> 64 channels, x2): multi-tile kernel geometry
+    u = fz.ups[2]
+    x16 = torch.randn(B, 300, u.mod.in_channels, device="cuda").half()
+    alpha = torch.softmax(torch.randn(B, u.mod.K, device="cuda"), 1)
+    y_cast = u.forward_cl(x16.float(), Fn._cache, alpha=alpha, act=N.ACT_LRELU)
+    y_in16 = u.forward_cl(x16, Fn._cache, alpha=alpha, act=N.ACT_LRELU, storage=torch.float32)
+    assert y_in16.dtype == torch.float32 and torch.equal(y_cast, y_in16)
+    # a geometry without the widening variant falls back to the cast inside forward_cl (first upsampler: K-loop kernel)
+    u0 = fz.ups[0]
+    x0 = torch.randn(B, 32, u0.mod.in_channels, device="cuda").half()
+    a0 = torch.softmax(torch.randn(B, u0.mod.K, device="cuda"), 1)
+    assert torch.equal(u0.forward_cl(x0.float(), Fn._cache, alpha=a0, act=N.ACT_LRELU),
+                       u0.forward_cl(x0, Fn._cache, alpha=a0, act=N.ACT_LRELU, storage=torch.float32))
+    # --- prologue
+    mel, spk, emo = torch.randn(B, 80, 32, device="cuda"), torch.randn(B, 192, device="cuda"), torch.randn(B, 384, device="cuda")
+    att = gen.input_proj.kernel_attention[1]
+    fp = gen.final_film.condition_projection
+    dt = torch.float16
+    c = Fn._cache
+    outs = []
+    for inputs in ((mel, spk, emo), (mel.half(), spk.half(), emo.half())):
+        m, s, e = (t.contiguous() for t in inputs)
+        alpha0 = torch.empty(B, att.weight.shape[0], device="cuda")
+        x = torch.empty(B, 32, 80, device="cuda", dtype=dt)
+        film = torch.empty(B, fp.out_features, device="cuda", dtype=dt)
+        rc = N.lib().mv_gen_prologue_in(P(m), P(c.get(att.weight, dt)), P(c.get(att.bias, dt)), P(s), P(e), P(c.get(fp.weight, dt)),
+                                        P(c.get(fp.bias, dt)), P(alpha0), P(x), P(film), None, 0, B, 80, 32, att.weight.shape[0], 192, 384,
+                                        fp.in_features, fp.out_features, ops._DT[m.dtype], ops._DT[dt], ops._stream())
+        assert rc == 0, rc
+        outs.append((alpha0, x, film))
+    torch.cuda.synchronize()
+    (a_f32, x_f32, f_f32), (a_f16, x_f16, f_f16) = outs
+    assert torch.equal(x_f32, x_f16)                                   # the channels-last copy rounds the same values
+    assert O.rel_l2(f_f32.float().cpu(), f_f16.float().cpu()) < 2e-3   # projection of unrounded vs fp16-rounded embeddings
+    assert float((a_f32 - a_f16).abs().max()) < 2e-3
+    rc = N.lib().mv_gen_prologue_in(P(mel.bfloat16()), None, None, None, None, None, None, None, None, None, None, 0, B, 80, 32, 4, 0, 0, 0, 0,
+                                    N.MV_BF16, N.MV_F16, ops._stream())
+    assert rc == -2                                                    # MV_ERR_DTYPE: inputs are the storage type or fp32 only
