@@ -620,19 +620,46 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict_
     for (int kb = 0; kb < KB; ++kb) al[kb] = kb < p.K ? alds[kb] : 0.f;
     const long bank_stride = (long)n_mt * KST * 512 * ES;
     const char* wlane = reinterpret_cast<const char*>(wp) + (long)lane * 8 * ES;
-#pragma unroll
-    for (int mw = 0; mw < MW; ++mw) {
-      const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
-#pragma unroll
-      for (int ks = 0; ks < KST; ++ks) {
-        typename WL::R wr[KB];
+    // The KB bank fragments of an operand are requested TOGETHER (fp32: those of operand i+1 while operand i is mixed) and the
+    // scheduling barriers keep loads and multiplies apart: left alone, the scheduler (minimising live registers next to the resident
+    // afr[][]) put every load right in front of its multiply - `global_load; s_waitcnt vmcnt(0)` 64 times in a row, one L2 round trip
+    // each: ~40 k cycles, half of the fp32 kernel.  (The 16-bit variants sit at the two-waves-per-SIMD register cliff, where any pinning of
+    // the schedule costs the second wave: they keep the compiler's order - their loads do overlap in part.)
+    if constexpr (ES == 4) {
+      typename WL::R wr[2][KB];
+      auto ldfrag = [&](int idx, int set) {
+        const int mw = idx / KST, ks = idx - mw * KST;
+        const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
         const char* wbase = wlane + ((long)mt * KST + ks) * 512 * ES;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) wr[kb] = WL::load(wbase + (kb < p.K ? kb : 0) * bank_stride);
+        for (int kb = 0; kb < KB; ++kb) wr[set][kb] = WL::load(wbase + (kb < p.K ? kb : 0) * bank_stride);
+      };
+      ldfrag(0, 0);
+#pragma unroll
+      for (int idx = 0; idx < MW * KST; ++idx) {
+        if (idx + 1 < MW * KST) ldfrag(idx + 1, (idx + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
         float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) WL::fma8(wr[kb], al[kb], f);
-        afr[mw][ks] = make_a<T>(f);
+        for (int kb = 0; kb < KB; ++kb) WL::fma8(wr[idx & 1][kb], al[kb], f);
+        afr[idx / KST][idx % KST] = make_a<T>(f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int mw = 0; mw < MW; ++mw) {
+        const int mt = (mt0 + mw) < n_mt ? (mt0 + mw) : (n_mt - 1);
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+          typename WL::R wr[KB];
+          const char* wbase = wlane + ((long)mt * KST + ks) * 512 * ES;
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) wr[kb] = WL::load(wbase + (kb < p.K ? kb : 0) * bank_stride);
+          float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) WL::fma8(wr[kb], al[kb], f);
+          afr[mw][ks] = make_a<T>(f);
+        }
       }
     }
   }
