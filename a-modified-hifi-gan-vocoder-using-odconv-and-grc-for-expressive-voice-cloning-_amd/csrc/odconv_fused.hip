@@ -119,12 +119,59 @@ __device__ long long* od_dbg = nullptr;
 // (sample, bank) pairs at a time and issues ALL their attention-weight loads before the first multiply - a `for (c = lane; c < Cin;
 // c += 64) acc += w[c] * m[c]` loop is one L2 round trip per 64 channels (8 in a row for the first upsampler's 512: 12 k of its 70 k
 // ticks went here, before anything else could start).
+constexpr int OD_LU = 8;                                   // 64-channel slices of attention weights a lane holds per (sample, bank) pair
+// The attention weights (and bias) of this wave's first two (sample, bank) pairs, requested before anything else in the prologue - they
+// depend on nothing, so the partial sums, their reduction and these loads are ONE memory round trip instead of three in a row (in-kernel
+// marks: partial sums 1.5 k, logits 3-6 k - a weight round trip, then the bias loaded after the wave tree - and softmax 2.5 k ticks).
+template <typename T>
+__device__ __forceinline__ bool od_logits_preload(float (&wv)[2][OD_LU], float (&bv)[2], int S, const OdP& p,
+                                                  const T* __restrict__ att_w, const T* __restrict__ att_b) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int Cin = p.Cin, npair = S * p.K;
+  if (npair > 8 || Cin > 64 * OD_LU) return false;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pr = wid * 2 + q < npair ? wid * 2 + q : npair - 1, kb = pr % p.K;
+#pragma unroll
+    for (int u = 0; u < OD_LU; ++u) {
+      const int cc = 64 * u + lane;
+      wv[q][u] = cc < Cin ? ld<T>(att_w + (long)kb * Cin + cc) : 0.f;
+    }
+    bv[q] = att_b ? ld<T>(att_b + kb) : 0.f;
+  }
+  return true;
+}
+
 template <typename T>
 __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int sstride, int S, const OdP& p,
-                                          const T* __restrict__ att_w, const T* __restrict__ att_b) {
+                                          const T* __restrict__ att_w, const T* __restrict__ att_b,
+                                          const float (*pre)[OD_LU] = nullptr, const float* preb = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int Cin = p.Cin, npair = S * p.K;
-  constexpr int U = 8;                                     // 64-channel slices per batch
+  constexpr int U = OD_LU;                                 // 64-channel slices per batch
+  if (pre) {                                               // npair <= 8, Cin <= 512: one batch, weights already in registers
+    const int pr0 = wid * 2;
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int pr = pr0 + q < npair ? pr0 + q : npair - 1, s = pr / p.K;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int cc = 64 * u + lane;
+        if (cc < Cin) acc[q] += pre[q][u] * scratch[s * sstride + cc];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float v = wave_sum(acc[q]);
+      const int pr = pr0 + q;
+      if (lane == 0 && pr < npair) {
+        const int s = pr / p.K, kb = pr % p.K;
+        alds[s * OD_MAXK + kb] = v / (float)p.Tin + preb[q];
+      }
+    }
+    return;
+  }
   for (int pr0 = wid * 2; pr0 < npair; pr0 += 8) {
     float acc[2] = {0.f, 0.f};
     for (int c0 = 0; c0 < Cin; c0 += 64 * U) {
@@ -174,6 +221,8 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
   const int tid = threadIdx.x;
   const int Cin = p.Cin;
   const int npc = p.pool_n / Cin;                       // partials per channel
+  float wpre[2][OD_LU], bpre[2];
+  const bool havew = od_logits_preload<T>(wpre, bpre, S, p, att_w, att_b);
   if (Cin <= 256) {
     const int G = 256 / Cin, c = tid % Cin, gq = tid / Cin;          // Cin is a multiple of 8; threads beyond G * Cin idle
     for (int s = 0; s < S; ++s) {
@@ -196,7 +245,7 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
       scratch[(s * G) * Cin + cc] = a;
     }
     __syncthreads();
-    od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b);
+    od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
   } else {
     // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel; a thread owns channels tid, tid + 256, ...
     for (int s = 0; s < S; ++s)
@@ -214,14 +263,17 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
         scratch[s * Cin + c] = a;                        // needs S * Cin floats of scratch
       }
     __syncthreads();
-    od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b);
+    od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
   }
   __syncthreads();
-  if (tid < S) {
-    float m = -INFINITY, den = 0.f;
-    for (int kb = 0; kb < p.K; ++kb) m = fmaxf(m, alds[tid * OD_MAXK + kb]);
-    for (int kb = 0; kb < p.K; ++kb) den += expf(alds[tid * OD_MAXK + kb] - m);
-    for (int kb = 0; kb < p.K; ++kb) alds[tid * OD_MAXK + kb] = expf(alds[tid * OD_MAXK + kb] - m) / den;
+  if (tid < S) {                                          // softmax over the banks, values in registers (one LDS round trip, not 3 K)
+    float z[OD_MAXK], m = -INFINITY, den = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < OD_MAXK; ++kb) { z[kb] = kb < p.K ? alds[tid * OD_MAXK + kb] : -INFINITY; m = fmaxf(m, z[kb]); }
+#pragma unroll
+    for (int kb = 0; kb < OD_MAXK; ++kb) { z[kb] = kb < p.K ? expf(z[kb] - m) : 0.f; den += z[kb]; }
+#pragma unroll
+    for (int kb = 0; kb < OD_MAXK; ++kb) if (kb < p.K) alds[tid * OD_MAXK + kb] = z[kb] / den;
   }
 }
 
