@@ -762,7 +762,10 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict_
         for (int mw = 0; mw < MW; ++mw) acc[mw][n] = M::mma(afr[mw][ks], bfr[DBUF ? (ks & 1) : 0][n], acc[mw][n]);
       if constexpr (DBUF) __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                                           // x tile consumed: reuse the region as the output tile
+    // fp32 storage: a lane's 4 accumulator rows are 4 consecutive output channels = one 16-byte store - straight to HBM, no output
+    // tile in LDS and two barriers per tile instead of four (16-bit storage needs the LDS tile to form 16-byte rows)
+    constexpr bool DIRECT = (ES == 4);
+    if constexpr (!DIRECT) __syncthreads();                    // x tile consumed: reuse the region as the output tile
     char* ol = xl;
 #pragma unroll
     for (int mw = 0; mw < MW; ++mw) {
@@ -783,12 +786,16 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict_
             ov[i] = actf(acc[mw][n][i] + bv[i]);
             if (ok) psum[mw][i] += M::round_store(ov[i]);
           }
-          M::store4(ol + ((long)(n * 16 + col)) * ORS + (row - R0) * ES, ov);
+          if constexpr (DIRECT) {
+            if (ok && row < p.M) M::store4(y + ((long)b * p.Tout + u) * p.Cout + (row - r * p.Cout), ov);
+          } else {
+            M::store4(ol + ((long)(n * 16 + col)) * ORS + (row - R0) * ES, ov);
+          }
         }
       }
     }
-    __syncthreads();
-    {
+    __syncthreads();                                           // (DIRECT: x tile consumed before the next one lands)
+    if constexpr (!DIRECT) {
       constexpr int EPC = 16 / ES, CPRO = RW / EPC;
       static_assert(256 % CPRO == 0, "store loop: fixed column per thread");
       const int ch = tid % CPRO, row = R0 + ch * EPC;
@@ -801,8 +808,8 @@ __global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict_
           const u32x4 val = *reinterpret_cast<const u32x4*>(ol + ((long)e) * ORS + ch * 16);
           *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(y + ((long)b * p.Tout + u) * p.Cout + o)) = val;
         }
+      __syncthreads();                                         // output tile drained before the next x tile lands
     }
-    __syncthreads();                                           // output tile drained before the next x tile lands
   }
   if (pooled_out) {                                            // one partial per (row, workgroup): slot blockIdx.x of this sample
 #pragma unroll
