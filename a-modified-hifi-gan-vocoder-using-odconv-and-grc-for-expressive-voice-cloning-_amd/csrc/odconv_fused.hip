@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x,
 // the current one (unconditional, row-clamped loads) and is committed to LDS after the current tile's stores, so no global-load
 // latency sits on the per-tile path.  16-bit storage, LeakyReLU / none, no FiLM.
 template <typename T, int MW, int NB, int CIN, int KB, typename TI = T>
-__global__ __launch_bounds__(256) void odconv_cl_mt_kernel(const TI* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
+__global__ __launch_bounds__(256, 2) void odconv_cl_mt_kernel(const TI* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
                                                            const float* __restrict__ alpha_in, const float* __restrict__ pooled_in,
                                                            const T* __restrict__ att_w, const T* __restrict__ att_b, T* __restrict__ y,
                                                            float* __restrict__ pooled_out, OdP p, int TL) {
