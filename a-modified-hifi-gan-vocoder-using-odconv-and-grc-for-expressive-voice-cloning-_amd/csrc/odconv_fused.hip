@@ -1359,6 +1359,11 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
           if (rc == MV_ERR_UNSUPPORTED) rc = od_kloop_launch<T, 1, 3, 1>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
         }
       }
+      // two samples per workgroup share the staged weights, but a grid that leaves CUs idle loses more: input_proj at B = 32 is
+      // 1 x 8 x 16 = 128 workgroups with S = 2 - one sample per workgroup fills the chip (17.7 -> ~14 us; MV_OD_S1=0: never)
+      static int s1 = -1;
+      if (s1 < 0) { const char* e = getenv("MV_OD_S1"); s1 = e ? atoi(e) : 1; }
+      if (rc == MV_ERR_UNSUPPORTED && s1 && (long)cdiv(B, 2) * cdiv(p.M, 64) * cdiv(ntiles, 3) < 256) OD_GO(1, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(2, 1, 3);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     } else if (wbytes > (1 << 20)) {         // big kernels, medium sequences: 144-column blocks amortise the aggregation
