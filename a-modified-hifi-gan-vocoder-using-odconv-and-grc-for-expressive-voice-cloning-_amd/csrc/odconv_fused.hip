@@ -1031,23 +1031,31 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
         for (int s = 0; s < S; ++s)
 #pragma unroll
           for (int n = 0; n < NB; ++n) boff[s][n] = (tap ? lbase[1][n] : lbase[0][n]) + (unsigned)(s * sample_stride) + koff0;
+        // B fragments of k-step j+1 are read while the MFMAs of k-step j run (two register sets; the scheduling barrier at the end
+        // of a k-step would otherwise hold every k-step's reads behind the previous k-step's MFMAs: LDS round trip + MFMAs in series)
+        constexpr bool BDB = (ES == 2);                // (fp32 operands are register pairs: a second set costs the second wave)
+        V bfr[BDB ? 2 : 1][S][NB];
+        auto ldb = [&](int j, int set) {
+#pragma unroll
+          for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) bfr[set][s][n] = M::load_bp(xl + boff[s][n] + j * 32 * LES, PLANE);
+        };
+        if constexpr (BDB) ldb(0, 0);
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
           V a0[MW];
 #pragma unroll
           for (int mw = 0; mw < MW; ++mw) a0[mw] = KW::op(ring[j][mw]);
-          // all B fragments first (independent LDS reads in flight together), then the MFMAs
-          V bfr[S][NB];
-#pragma unroll
-          for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int n = 0; n < NB; ++n) bfr[s][n] = M::load_bp(xl + boff[s][n] + j * 32 * LES, PLANE);
+          if constexpr (BDB) { if (j + 1 < PD) ldb(j + 1, (j + 1) & 1); }
+          else ldb(j, 0);
+          if constexpr (BDB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
-              for (int mw = 0; mw < MW; ++mw) acc[mw][s][n] = M::mma(a0[mw], bfr[s][n], acc[mw][s][n]);
+              for (int mw = 0; mw < MW; ++mw) acc[mw][s][n] = M::mma(a0[mw], bfr[BDB ? (j & 1) : 0][s][n], acc[mw][s][n]);
           // refill this ring slot for the next chunk NOW (it is consumed PD k-steps from here).  Left to itself the scheduler
           // sinks all PD loads to the end of the chunk - right in front of their first use - and every chunk then starts by
           // waiting out a full L2 round trip; the scheduling barrier pins the load behind this k-step's MFMAs.
