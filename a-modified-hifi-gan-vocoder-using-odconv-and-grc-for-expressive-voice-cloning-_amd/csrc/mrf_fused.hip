@@ -478,12 +478,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
         // front of its first use (r, s_waitcnt lgkmcnt(0), MFMA, r, wait, MFMA ... in the ISA) and each MFMA pays an LDS round trip
         __builtin_amdgcn_sched_barrier(0);
         const int tap = sidx >> 1, set = sidx & 1;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
           if (mrf_std_frag(m, tap) >= 0) {
 #pragma unroll
             for (int n = 0; n < NTW; ++n) v[m][n] = M::mma(afr[set][m], bfr[set][n], v[m][n]);
           }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else
