@@ -35,4 +35,4 @@ with open(dst, "w", newline="") as fh:
 print("wrote", dst)
 PY
 mkdir -p gpurun_out/${TAG}_profiles && cp profiles/${TAG}_fp32_pipe_counters.csv gpurun_out/${TAG}_profiles/
-find $OUT -name "*.db" -delete
+rm -rf $OUT    # the raw csv files are large; the summary is what is kept
