@@ -113,8 +113,12 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
   }
 
 // internal cross-file entry (conv_out.hip), not part of the C ABI
+// (part8 / tab8 / nwg / eps: the fp32 MFMA form forms the deferred GroupNorm affine itself from the last block's partial sums and
+//  `ab` is not read - mvi_conv_out_affine_takes_partials says whether that form will run)
+bool mvi_conv_out_affine_takes_partials(int dtype, int ks);
 int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
-                        int pad, int act, int dtype, hipStream_t stream);
+                        int pad, int act, int dtype, hipStream_t stream, const float* part8 = nullptr, const float* tab8 = nullptr,
+                        int nwg = 0, float eps = 0.f);
 
 #define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
 // runtime calls that are not kernel launches: propagate the hipError_t as the entry point's (positive) return code

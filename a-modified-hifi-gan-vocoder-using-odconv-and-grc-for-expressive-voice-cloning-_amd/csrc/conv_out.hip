@@ -189,7 +189,9 @@ __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restri
 template <int C>
 __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* __restrict__ f, const float* __restrict__ x,
                                                                    const float* __restrict__ ab, const float* __restrict__ w, float bias,
-                                                                   float* __restrict__ y, int Tn, int ks, int pad, int act) {
+                                                                   float* __restrict__ y, int Tn, int ks, int pad, int act,
+                                                                   const float* __restrict__ part8, const float* __restrict__ tab8, int nwg,
+                                                                   float eps) {
   static_assert(C == 64, "two 32-channel k-steps");
   using M = Mma<float>;
   using V = M::V;
@@ -206,8 +208,22 @@ __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* 
   const float* fb = f + (size_t)b * Tn * C;
   const int ch = tid % CPR;
   float ra[4], rb[4];
+  if (part8) {   // the last MRF block's GroupNorm(8,64) affine straight from its per-workgroup partial sums (the sums of mrf_affine_kernel,
+                 // in its order): a = rstd * gamma, b = beta - mean * a; this thread's 4 channels share one group
+    const int q = (ch * 4) >> 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < nwg; ++i) {
+      s1 += part8[((size_t)(b * nwg + i) * 8 + q) * 2];
+      s2 += part8[((size_t)(b * nwg + i) * 8 + q) * 2 + 1];
+    }
+    const float n = 8.f * (float)Tn, mu = s1 / n;
+    const float rs = rsqrtf(fmaxf(s2 / n - mu * mu, 0.f) + eps);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { ra[j] = ab[(size_t)b * 2 * C + ch * 4 + j]; rb[j] = ab[(size_t)b * 2 * C + C + ch * 4 + j]; }
+    for (int j = 0; j < 4; ++j) { ra[j] = rs * tab8[320 + ch * 4 + j]; rb[j] = tab8[384 + ch * 4 + j] - mu * ra[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ra[j] = ab[(size_t)b * 2 * C + ch * 4 + j]; rb[j] = ab[(size_t)b * 2 * C + C + ch * 4 + j]; }
+  }
   // A operand: row = tap (lane & 15), k = 32 * kstep + 8 * (lane >> 4) + e  ->  w[tap][k]  (w is [ks][C] fp32)
   V a[2];
 #pragma unroll
@@ -278,9 +294,16 @@ __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* 
 using namespace mv;
 
 // internal (not part of the C ABI): used by the MRF chain's fused ending, mrf_fused.hip
+bool mvi_conv_out_affine_takes_partials(int dtype, int ks) {
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("MV_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  return dtype == MV_F32 && use_mfma && ks <= 16;
+}
+
 int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
-                        int pad, int act, int dtype, hipStream_t stream) {
+                        int pad, int act, int dtype, hipStream_t stream, const float* part8, const float* tab8, int nwg, float eps) {
   if (C != 64 || 2 * pad != ks - 1) return MV_ERR_UNSUPPORTED;
+  if (part8 && !mvi_conv_out_affine_takes_partials(dtype, ks)) return MV_ERR_UNSUPPORTED;
   dim3 grid(cdiv(T_, 256), B);
   static int use_mfma = -1;
   if (use_mfma < 0) { const char* e = getenv("MV_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
@@ -290,7 +313,8 @@ int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const flo
     auto kern = conv_out_affine_mfma_kernel<64>;
     static size_t lds_set_m = 0;
     if (lds > lds_set_m) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set_m = lds; }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)f, (const float*)x, ab, wt, bias, (float*)y, T_, ks, pad, act);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)f, (const float*)x, ab, wt, bias, (float*)y, T_, ks, pad, act,
+                       part8, tab8, nwg, eps);
     return MV_OK;
   }
   MV_DISPATCH(dtype, {

@@ -826,7 +826,8 @@ __global__ __launch_bounds__(64) void mrf_affine_kernel(const float* __restrict_
 template <typename T, int NWAVES, int NTW>
 static int mrf_chain_launch(const void* x, void* out, const void* const* packed, const MrfMeta* metas, int nblocks, char* ws,
                             int B, int Tn, float eps, hipStream_t stream, float* ab_out = nullptr, const void** f_last = nullptr,
-                            const void** x_last = nullptr) {
+                            const void** x_last = nullptr, const float** part8_last = nullptr, const float** tab_last = nullptr,
+                            int* nwg_last = nullptr) {
   using M = Mma<T>;
   constexpr int FS = M::NSETS * FRAG_BYTES;
   constexpr int RS = (M::ES == 4 ? 2 * MRF_C * 2 : MRF_C * M::ES) + 32;   // as in the kernel
@@ -878,8 +879,9 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
   }
   if (ab_out) {
     constexpr size_t WB = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
-    hipLaunchKernelGGL(mrf_affine_kernel, dim3(B), dim3(64), 0, stream, part8,
-                       reinterpret_cast<const float*>((const char*)packed[nblocks - 1] + WB), ab_out, nwg, Tn, eps);
+    const float* tabp = reinterpret_cast<const float*>((const char*)packed[nblocks - 1] + WB);
+    if (part8_last) { *part8_last = part8; *tab_last = tabp; *nwg_last = nwg; }      // the consumer forms the affine itself
+    else hipLaunchKernelGGL(mrf_affine_kernel, dim3(B), dim3(64), 0, stream, part8, tabp, ab_out, nwg, Tn, eps);
     *f_last = fbuf;
     *x_last = xi;
     return MV_OK;
@@ -987,10 +989,13 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
   const void* fl = nullptr;
   const void* xl_ = nullptr;
   int rc;
+  const bool fold = mvi_conv_out_affine_takes_partials(dtype, ks);     // the output conv forms the last block's affine itself: one launch less
+  const float* p8 = nullptr; const float* tb8 = nullptr; int nwg8 = 0;
   switch (dtype) {
     case MV_F32:
-      rc = mrf_chain_launch<float, 8, 1>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_);
-      if (rc == MV_ERR_UNSUPPORTED) rc = mrf_chain_launch<float, 4, 2>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_);
+      rc = mrf_chain_launch<float, 8, 1>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8);
+      if (rc == MV_ERR_UNSUPPORTED)
+        rc = mrf_chain_launch<float, 4, 2>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8);
       break;
     case MV_BF16: rc = mrf_chain_launch<bf16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
     case MV_F16: rc = mrf_chain_launch<f16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
@@ -999,7 +1004,7 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   // conv_packed = mv_conv_out_pack_all image: the fp32 [ks][64] weights come first
-  rc = mvi_conv_out_affine(fl, xl_, ab, (const float*)conv_packed, conv_bias, wave, B, T_, MRF_C, ks, ks / 2, act, dtype, st);
+  rc = mvi_conv_out_affine(fl, xl_, ab, (const float*)conv_packed, conv_bias, wave, B, T_, MRF_C, ks, ks / 2, act, dtype, st, p8, tb8, nwg8, eps);
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   return MV_OK;
