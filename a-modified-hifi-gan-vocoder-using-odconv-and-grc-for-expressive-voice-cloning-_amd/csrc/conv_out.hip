@@ -167,6 +167,68 @@ __global__ __launch_bounds__(256) void conv_out_dot2_kernel(const T* __restrict_
   if (t < Tn) st<T>(y + (size_t)b * Tn + t, apply_act((acc0 + acc1) + (acc2 + acc3), act, 0.f));
 }
 
+// 16-bit storage with the taps on the MFMA rows (as conv_out_affine_mfma_kernel below does for fp32): z[tap][pos] = sum_c w[tap][c] x[pos][c]
+// (A = the [ks][C] weight image of this type, 16-byte fragments straight from it; B = the staged rows as they are; 2 k-steps per 16
+// positions, every row read once), then y[t] = bias + sum_tap z[tap][t + tap] from a z tile that takes the rows' place in LDS.  The dot2
+// form reads every row ks times and fetches its weight pairs through scalar loads inside the tap loop.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void conv_out_mfma16_kernel(const T* __restrict__ x, const T* __restrict__ wimg, float bias,
+                                                              T* __restrict__ y, int Tn, int ks, int pad, int act) {
+  static_assert(C == 64 && sizeof(T) == 2, "two 32-channel k-steps of a 16-bit type");
+  using M = Mma<T>;
+  using V = typename M::V;
+  constexpr int TS = 256, ES = 2, RS = C * ES + 16, CPR = C * ES / 16;
+  extern __shared__ __align__(16) char lds[];
+  const int b = blockIdx.y, t0 = blockIdx.x * TS, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int rows = TS + ks - 1, nblk = (rows + 15) / 16;
+  const T* xb = x + (size_t)b * Tn * C;
+  V a[2];
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2) {
+    alignas(16) T wv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st<T>(wv + e, 0.f);
+    if (col < ks) *reinterpret_cast<u32x4*>(wv) = *reinterpret_cast<const u32x4*>(wimg + col * C + k2 * 32 + 8 * g);
+    a[k2] = M::load_b(wv);
+  }
+  stage_batched<9, 256>(tid, nblk * 16 * CPR, lds, [&](int i, const void*& src, int& dst) {   // rows past `rows`: zeros (src stays null)
+    const int r = i / CPR, ch = i % CPR;
+    const int t = t0 - pad + r;
+    if (r < rows && t >= 0 && t < Tn) src = reinterpret_cast<const char*>(xb + (size_t)t * C) + ch * 16;
+    dst = r * RS + ch * 16;
+  });
+  __syncthreads();
+  constexpr int MAXB = 5;                   // position blocks per wave: 17 blocks over 4 waves
+  f32x4 z[MAXB];
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pb = wid + 4 * i;
+    if (pb < nblk) {
+      const char* brow = lds + (size_t)(pb * 16 + col) * RS + g * 16;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) z[i] = M::mma(a[k2], M::load_b(brow + k2 * 64), z[i]);
+    }
+  }
+  __syncthreads();                          // every wave is done with the rows: the z tile takes their place
+  constexpr int ZS = TS + 32;
+  float* zt = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < MAXB; ++i) {
+    const int pb = wid + 4 * i;
+    if (pb < nblk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zt[(4 * g + r) * ZS + pb * 16 + col] = z[i][r];
+    }
+  }
+  __syncthreads();
+  float acc = bias;
+  for (int j = 0; j < ks; ++j) acc += zt[j * ZS + tid + j];
+  const int t = t0 + tid;
+  if (t < Tn) st<T>(y + (size_t)b * Tn + t, apply_act(acc, act, 0.f));
+}
+
 // all three images of w [1][C][ks]: fp32 [ks][C] | bf16 [ks][C] | f16 [ks][C]
 template <typename P>
 __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restrict__ out, int C, int ks) {
@@ -380,6 +442,19 @@ extern "C" int mv_conv_out_act_packed_cl(const void* x, const void* packed, floa
   const char* pk = (const char*)packed;
   if (dtype == MV_F32) return mv_conv_out_act_cl(x, (const float*)pk, bias, y, B, T_, C, ks, pad, act, dtype, stream);
   dim3 grid(cdiv(T_, 256), B);
+  static int use_mfma = -1;
+  if (use_mfma < 0) { const char* e = getenv("MV_CONV_OUT_MFMA"); use_mfma = e ? atoi(e) : 1; }
+  if (use_mfma && ks <= 16 && (dtype == MV_BF16 || dtype == MV_F16)) {
+    const size_t ldsm = (size_t)((256 + ks - 1 + 15) / 16) * 16 * (64 * 2 + 16);      // >= the z tile (16 x 288 floats = 18 KB)
+    if (dtype == MV_BF16)
+      hipLaunchKernelGGL((conv_out_mfma16_kernel<bf16, 64>), grid, dim3(256), ldsm, (hipStream_t)stream, (const bf16*)x,
+                         (const bf16*)(pk + (size_t)C * ks * 4), bias, (bf16*)y, T_, ks, pad, act);
+    else
+      hipLaunchKernelGGL((conv_out_mfma16_kernel<f16, 64>), grid, dim3(256), ldsm, (hipStream_t)stream, (const f16*)x,
+                         (const f16*)(pk + (size_t)C * ks * 6), bias, (f16*)y, T_, ks, pad, act);
+    MV_LAUNCH_CHECK();
+    return MV_OK;
+  }
   const size_t lds = (size_t)(256 + ks - 1) * (64 * 2 + 16);
   if (lds > 64 * 1024) return MV_ERR_UNSUPPORTED;
   if (dtype == MV_BF16)
