@@ -118,7 +118,11 @@ __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 bool mvi_conv_out_affine_takes_partials(int dtype, int ks);
 int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
                         int pad, int act, int dtype, hipStream_t stream, const float* part8 = nullptr, const float* tab8 = nullptr,
-                        int nwg = 0, float eps = 0.f);
+                        int nwg = 0, float eps = 0.f, int x_pair = 0);
+// internal cross-file entry (mrf_stream.hip): the MRF chain in its streaming form (MV_F32_W16, dilations (1, 3, 5) only)
+int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, int nblocks, char* ws, size_t act_bytes, int B, int Tn,
+                         float eps, hipStream_t stream, const void** f_last, const void** x_last, int* x_last_pair,
+                         const float** part8_last, const float** tab_last, int* nwg_last);
 
 #define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
 // runtime calls that are not kernel launches: propagate the hipError_t as the entry point's (positive) return code

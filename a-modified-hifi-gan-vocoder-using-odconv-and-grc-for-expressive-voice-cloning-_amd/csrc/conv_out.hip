@@ -248,7 +248,7 @@ __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restri
 //   z[tap][pos] = sum_c w[tap][c] * row[pos][c]   (A = the weights as a 16 x 64 operand, zero beyond ks; B = the staged rows, PRE-SPLIT
 //   into hi + lo bf16 planes when they are committed; 2 k-steps x 3 products per 16 positions, every row read ONCE),
 //   y[t] = bias + sum_tap z[tap][t + tap]          (the z tile replaces the rows in LDS after a barrier; 11 adds per output).
-template <int C>
+template <int C, bool XPAIR>     // XPAIR: x arrives as pair rows (8 groups of [8 x f16 hi | 8 x f16 lo], mrf_stream.hip) instead of fp32 rows
 __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* __restrict__ f, const float* __restrict__ x,
                                                                    const float* __restrict__ ab, const float* __restrict__ w, float bias,
                                                                    float* __restrict__ y, int Tn, int ks, int pad, int act,
@@ -303,7 +303,14 @@ __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* 
       const int r = r0 + u * (256 / CPR), t = t0 - pad + r;
       ok[u] = r < rows && t >= 0 && t < Tn;
       const size_t off = (size_t)(ok[u] ? t : 0) * C + ch * 4;
-      xv[u] = *reinterpret_cast<const f32x4*>(xb + off);
+      if constexpr (XPAIR) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+        const char* px = reinterpret_cast<const char*>(xb) + (size_t)(ok[u] ? t : 0) * (C * 4) + (ch >> 1) * 32 + (ch & 1) * 8;
+        const f16x4_t h = *reinterpret_cast<const f16x4_t*>(px), l = *reinterpret_cast<const f16x4_t*>(px + 16);
+        xv[u] = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+      } else {
+        xv[u] = *reinterpret_cast<const f32x4*>(xb + off);
+      }
       fv[u] = *reinterpret_cast<const f32x4*>(fb + off);
     }
 #pragma unroll
@@ -363,8 +370,10 @@ bool mvi_conv_out_affine_takes_partials(int dtype, int ks) {
 }
 
 int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const float* wt, float bias, void* y, int B, int T_, int C, int ks,
-                        int pad, int act, int dtype, hipStream_t stream, const float* part8, const float* tab8, int nwg, float eps) {
+                        int pad, int act, int dtype, hipStream_t stream, const float* part8, const float* tab8, int nwg, float eps,
+                        int x_pair) {
   if (C != 64 || 2 * pad != ks - 1) return MV_ERR_UNSUPPORTED;
+  if (x_pair && !(dtype == MV_F32 && mvi_conv_out_affine_takes_partials(dtype, ks))) return MV_ERR_UNSUPPORTED;
   if (part8 && !mvi_conv_out_affine_takes_partials(dtype, ks)) return MV_ERR_UNSUPPORTED;
   dim3 grid(cdiv(T_, 256), B);
   static int use_mfma = -1;
@@ -372,9 +381,12 @@ int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const flo
   if (dtype == MV_F32 && use_mfma && ks <= 16) {
     const size_t rows16 = (size_t)((256 + ks - 1 + 15) / 16) * 16;
     const size_t lds = rows16 * (2 * 64 * 2 + 16);       // >= the z tile (16 x 288 floats)
-    auto kern = conv_out_affine_mfma_kernel<64>;
-    static size_t lds_set_m = 0;
-    if (lds > lds_set_m) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set_m = lds; }
+    auto kern = x_pair ? conv_out_affine_mfma_kernel<64, true> : conv_out_affine_mfma_kernel<64, false>;
+    static size_t lds_set_m[2] = {0, 0};
+    if (lds > lds_set_m[x_pair ? 1 : 0]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      lds_set_m[x_pair ? 1 : 0] = lds;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)f, (const float*)x, ab, wt, bias, (float*)y, T_, ks, pad, act,
                        part8, tab8, nwg, eps);
     return MV_OK;

@@ -43,7 +43,9 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16> {
   static constexpr int NSETS = 1;          // operand images per weight fragment
   static constexpr int ES = 2;             // storage element size
+  using ST = bf16;                         // storage type in HBM
   struct V { bf16x8_t v; };
+  using VA = V; using VB = V;              // weight (A) / activation (B) operand types
   static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
   }
@@ -73,7 +75,9 @@ template <> struct Mma<bf16> {
 template <> struct Mma<f16> {
   static constexpr int NSETS = 1;
   static constexpr int ES = 2;
+  using ST = f16;
   struct V { f16x8_t v; };
+  using VA = V; using VB = V;
   static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
   }
@@ -102,7 +106,10 @@ template <> struct Mma<f16> {
 template <> struct Mma<float> {
   static constexpr int NSETS = 2;          // hi image + lo image
   static constexpr int ES = 4;
+  using ST = float;
   struct V { bf16x8_t hi, lo; };
+  using VA = V; using VB = V;
+  static __device__ __forceinline__ void load4p(const void* p, float* o) { Mma<bf16>::load4(p, o); }   // 4 elements of one split plane
   static __device__ __forceinline__ f32x4 mma(const V& a, const V& b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
@@ -158,6 +165,55 @@ template <> struct Mma<float> {
   static __device__ __forceinline__ float round_store(float v) { return v; }
 };
 
+// fp32 storage, TWO products per MAC: activations split hi = f16(x), lo = f16(x - hi) (22 significant bits), weights a SINGLE f16
+// (the f16 packed image): a.w * b.hi + a.w * b.lo.  One third fewer MFMAs and half the weight bytes of the bf16x3 mode; the price is the
+// weights' rounding (2^-12 relative; tools/error_budget.py: +1.1e-4 in quadrature on the C2 waveform for the three MRF blocks).
+struct f32w16 {};
+template <> struct Mma<f32w16> {
+  static constexpr int NSETS = 1;
+  static constexpr int ES = 4;
+  using ST = float;
+  struct VA { f16x8_t v; };
+  struct VB { f16x8_t hi, lo; };
+  static __device__ __forceinline__ f32x4 mma(const VA& a, const VB& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.lo, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.hi, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ VA load_a(const char* p, int) {
+    VA r; r.v = *reinterpret_cast<const f16x8_t*>(p); return r;
+  }
+  static __device__ __forceinline__ VB load_bp(const void* p, int plane) {
+    VB r;
+    r.hi = *reinterpret_cast<const f16x8_t*>(p);
+    r.lo = *reinterpret_cast<const f16x8_t*>(reinterpret_cast<const char*>(p) + plane);
+    return r;
+  }
+  // hi by round-to-nearest-even (v_cvt_f16_f32), lo = f16(x - hi): exact difference, 11 more bits
+  static __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    hi = pack_f16((float)ha, (float)hb);
+    lo = pack_f16(a - (float)ha, b - (float)hb);
+  }
+  static __device__ __forceinline__ void split4(const f32x4& a, u32x2& hi, u32x2& lo) {
+    uint32_t h0, h1, l0, l1;
+    split2(a[0], a[1], h0, l0);
+    split2(a[2], a[3], h1, l1);
+    hi = u32x2{h0, h1}; lo = u32x2{l0, l1};
+  }
+  static __device__ __forceinline__ VB from_acc(const f32x4& x, const f32x4& y) {
+    uint32_t h[4], l[4];
+    split2(x[0], x[1], h[0], l[0]); split2(x[2], x[3], h[1], l[1]);
+    split2(y[0], y[1], h[2], l[2]); split2(y[2], y[3], h[3], l[3]);
+    const u32x4 uh = {h[0], h[1], h[2], h[3]}, ul = {l[0], l[1], l[2], l[3]};
+    VB r; r.hi = __builtin_bit_cast(f16x8_t, uh); r.lo = __builtin_bit_cast(f16x8_t, ul); return r;
+  }
+  static __device__ __forceinline__ void load4(const void* p, float* o) { Mma<float>::load4(p, o); }
+  static __device__ __forceinline__ void store4(void* p, const float* v) { Mma<float>::store4(p, v); }
+  static __device__ __forceinline__ void load4p(const void* p, float* o) { Mma<f16>::load4(p, o); }
+  static __device__ __forceinline__ float round_store(float v) { return v; }
+};
+template <typename T> using StT = typename Mma<T>::ST;
+
 // store one weight value into a packed A-fragment image set (pack kernels)
 template <typename T> struct PackW;
 template <> struct PackW<bf16> {
@@ -170,6 +226,7 @@ template <> struct PackW<f16> {
     reinterpret_cast<f16*>(frag + lane * 16)[j] = (f16)v;
   }
 };
+template <> struct PackW<f32w16> : PackW<f16> {};
 template <> struct PackW<float> {
   static __device__ __forceinline__ void put(char* frag, int img_stride, int lane, int j, float v) {
     const bf16 h = __float2bfloat16(v);

@@ -27,56 +27,12 @@
 // Workgroup = NWAVES waves, each wave owns NTW*16 consecutive time steps of one sample and stages its own
 // x tile (+halo) into a private LDS region (no block barrier on the data path); packed weights (48 KB) are
 // staged once per workgroup.
-#include "mfma.h"
+#include "mrf_common.h"
 #include <cstring>
 #include <type_traits>
 #include <cstdio>
 
 namespace mv {
-
-constexpr int MRF_C = 64;        // residual-stream channels
-constexpr int MRF_CPD = 20;      // channels per dilation branch
-constexpr int MRF_NBR = 3;
-constexpr int MRF_MAXTAPS = 8;
-constexpr int MRF_CONV_FRAGS = 32, MRF_RES_FRAGS = 8, MRF_FUS_FRAGS = 8;
-constexpr int MRF_TAB_FLOATS = 7 * 64;
-
-struct MrfMeta {
-  int ntaps, halo;
-  int tap_off[MRF_MAXTAPS];
-  int frag_of[4][MRF_MAXTAPS];   // fragment-pair index of (M-tile, tap) or -1
-  int dil[MRF_NBR];
-};
-
-static inline bool mrf_make_meta(const int* dil, MrfMeta* m) {
-  int offs[MRF_MAXTAPS], n = 0;
-  auto add = [&](int o) {
-    for (int i = 0; i < n; ++i) if (offs[i] == o) return;
-    if (n < MRF_MAXTAPS) offs[n++] = o; else n = MRF_MAXTAPS + 1;
-  };
-  add(0);
-  for (int i = 0; i < MRF_NBR; ++i) { if (dil[i] < 1 || dil[i] > 8) return false; add(-dil[i]); add(dil[i]); }
-  if (n > 7) return false;
-  for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (offs[j] < offs[i]) { int t = offs[i]; offs[i] = offs[j]; offs[j] = t; }
-  m->ntaps = n; m->halo = 0;
-  for (int i = 0; i < MRF_MAXTAPS; ++i) m->tap_off[i] = i < n ? offs[i] : 0;
-  for (int i = 0; i < MRF_NBR; ++i) { m->dil[i] = dil[i]; if (dil[i] > m->halo) m->halo = dil[i]; }
-  int next = 0;
-  for (int mt = 0; mt < 4; ++mt) {
-    for (int t = 0; t < MRF_MAXTAPS; ++t) m->frag_of[mt][t] = -1;
-    for (int row = 16 * mt; row < 16 * mt + 16 && row < MRF_NBR * MRF_CPD; ++row) {
-      const int br = row / MRF_CPD;
-      for (int t = 0; t < n; ++t)
-        if ((offs[t] == 0 || offs[t] == dil[br] || offs[t] == -dil[br]) && m->frag_of[mt][t] < 0) m->frag_of[mt][t] = -2;
-    }
-    for (int t = 0; t < n; ++t) if (m->frag_of[mt][t] == -2) m->frag_of[mt][t] = next++;
-  }
-  return next * 2 <= MRF_CONV_FRAGS;
-}
-
-template <typename T> constexpr size_t mrf_packed_bytes() {
-  return (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * Mma<T>::NSETS * FRAG_BYTES + MRF_TAB_FLOATS * 4;
-}
 
 // ------------------------------------------------------------------------------------------------ pack
 struct MrfRawParams {   // mirrors mv_mrf_params (include/mi355x_vocoder.h)
@@ -167,23 +123,6 @@ __global__ __launch_bounds__(256) void mrf_pack_kernel(MrfRawParams p, MrfMeta m
 // The reference's (and the default generator's) dilations are (1, 3, 5): for that case the tap table is a compile-time
 // constant, so stage 1 becomes straight-line code that the kernel software-pipelines (operands of k-step s+1 are read
 // from LDS while the MFMAs of k-step s run).  Any other dilation set takes the table from MrfMeta at run time.
-__host__ __device__ constexpr int mrf_std_off(int tap) { return tap == 0 ? -5 : tap == 1 ? -3 : tap == 2 ? -1 : tap == 3 ? 0 : tap == 4 ? 1 : tap == 5 ? 3 : 5; }
-__host__ __device__ constexpr int mrf_std_frag(int m, int tap) {
-  // mrf_make_meta's numbering for dil = {1,3,5}: M-tile 0 uses taps 2,3,4; 1: 1..5; 2: 0,1,3,5,6; 3: 0,3,6
-  return m == 0 ? (tap >= 2 && tap <= 4 ? tap - 2 : -1)
-       : m == 1 ? (tap >= 1 && tap <= 5 ? 3 + tap - 1 : -1)
-       : m == 2 ? (tap == 0 ? 8 : tap == 1 ? 9 : tap == 3 ? 10 : tap == 5 ? 11 : tap == 6 ? 12 : -1)
-                : (tap == 0 ? 13 : tap == 3 ? 14 : tap == 6 ? 15 : -1);
-}
-static inline bool mrf_meta_is_std(const MrfMeta& m) {
-  if (m.ntaps != 7 || m.halo != 5) return false;
-  for (int t = 0; t < 7; ++t) {
-    if (m.tap_off[t] != mrf_std_off(t)) return false;
-    for (int a = 0; a < 4; ++a) if (m.frag_of[a][t] != mrf_std_frag(a, t)) return false;
-  }
-  return true;
-}
-
 constexpr int MRF_HMAX = 8;   // largest dilation the fused kernel accepts (prefetch registers are sized for it)
 
 // one 16-byte chunk of storage elements <-> floats (8 for 16-bit storage, 4 for fp32)
@@ -222,15 +161,17 @@ template <> struct Chunk<float> {
 __device__ long long* mrf_dbg = nullptr;
 #endif
 template <typename T, int NWAVES, int NTW, int PASS, bool STD>
-__global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ x, T* __restrict__ out,
+__global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const StT<T>* __restrict__ x, StT<T>* __restrict__ out,
                                                           const char* __restrict__ packed, MrfMeta meta,
                                                           const float* __restrict__ part5, float* __restrict__ part5_out,
                                                           const float* __restrict__ part8, float* __restrict__ part8_out,
                                                           const uint8_t* __restrict__ mask, float mask_scale,
                                                           int Tn, int nwg, int nit, float eps,
-                                                          const T* __restrict__ fprev, const char* __restrict__ packed_prev) {
+                                                          const StT<T>* __restrict__ fprev, const char* __restrict__ packed_prev) {
   using M = Mma<T>;
-  using V = typename M::V;
+  using ST = StT<T>;                                  // storage type (T is the operand mode: bf16, f16, float = bf16x3, f32w16)
+  using VA = typename M::VA;
+  using VB = typename M::VB;
   // PASS 1/2/3: the per-block passes (statistics of v, statistics of f, output).  Chain passes: 4 = A (tile rows are
   // a*fprev + b + x, written to `out`; statistics of v), 5 = B (writes f to `out`; statistics of f), 6 = F (rows as in A, write only)
   constexpr bool RECON = (PASS == 4 || PASS == 6);
@@ -279,6 +220,7 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   const int H = meta.halo;
 #ifdef MV_MRF_TIMING
   long long tmk[12]; int ntm = 0;
+  const long long t_abs0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide: when this wave started
 #define MRF_TM() do { if (ntm < 12) tmk[ntm++] = clock64(); } while (0)
   MRF_TM();
 #else
@@ -290,14 +232,14 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   const int sidx = SHARED ? tid : lane;                                  // staging piece index of this thread: sidx + SSTEP * i
   constexpr int SSTEP = SHARED ? NT : 64;
   const int own_rows = SHARED ? NWAVES * TW : TW;
-  const T* xb = x + (size_t)b * Tn * MRF_C;
+  const ST* xb = x + (size_t)b * Tn * MRF_C;
 
   // ---- software pipeline: the NEXT tile's rows travel HBM -> registers while the current tile is computed
-  using CK = Chunk<T>;
+  using CK = Chunk<ST>;
   constexpr int NPF = RECON ? NLD : 1;
   u32x4 pre[NLD], pref[NPF];                         // x rows; chain passes A / F: the previous block's f rows as well
-  const T* fb = RECON ? fprev + (size_t)b * Tn * MRF_C : nullptr;
-  T* ob = out + (size_t)b * Tn * MRF_C;
+  const ST* fb = RECON ? fprev + (size_t)b * Tn * MRF_C : nullptr;
+  ST* ob = out + (size_t)b * Tn * MRF_C;
   float ra[CK::N], rb[CK::N];                        // chain passes A / F: this lane's chunk of the deferred GN8 affine (set below)
   auto tile_t0 = [&](int it) { return ((wg * nit + it) * NWAVES + wid) * TW; };     // first output step of this WAVE
   auto stage_t0 = [&](int it) { return SHARED ? (wg * nit + it) * NWAVES * TW : tile_t0(it); };   // ... of the staged tile
@@ -372,8 +314,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     const int pi = tid >> 4, pq = tid & 15;                 // (workgroup index, group) for GN5; GN8 uses threads 256..
     if (NEED5 && pi < nwg && tid < 256) pp = *reinterpret_cast<const float2*>(part5 + ((size_t)(b * nwg + pi) * 16 + pq) * 2);
     float2 pp8 = {0.f, 0.f};
-    const int t8 = tid - 256, pi8 = t8 >> 3, pq8 = t8 & 7;
-    if (NEED8 && NWAVES * 64 >= 512 && t8 >= 0 && pi8 < nwg && t8 < 128) pp8 = *reinterpret_cast<const float2*>(part8 + ((size_t)(b * nwg + pi8) * 8 + pq8) * 2);
+    const int t8 = (NWAVES * 64 >= 512) ? tid - 256 : tid, pi8 = t8 >> 3, pq8 = t8 & 7;   // (4-wave workgroups: the GN5 threads load these too)
+    if (NEED8 && t8 >= 0 && pi8 < nwg && t8 < 128) pp8 = *reinterpret_cast<const float2*>(part8 + ((size_t)(b * nwg + pi8) * 8 + pq8) * 2);
     if constexpr (NEED_W) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
@@ -385,9 +327,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     float2* sc5 = reinterpret_cast<float2*>(xl);
     float2* sc8 = sc5 + 256;
     if (NEED5 && tid < 256) sc5[tid] = pp;
-    if (NEED8 && NWAVES * 64 >= 512 && t8 >= 0 && t8 < 128) sc8[t8] = pp8;
+    if (NEED8 && t8 >= 0 && t8 < 128) sc8[t8] = pp8;
   }
-  const bool fast_stats = nwg <= 16 && NWAVES * 64 >= 512;
+  const bool fast_stats = nwg <= 16 && NWAVES * 64 >= 256;
   if (NEED5 || NEED8) __syncthreads();
   if (NEED5 && tid < 16) {
     float s1 = 0.f, s2 = 0.f;
@@ -461,7 +403,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
     if (STD) {
       // straight-line, software-pipelined: step s = (tap, ks); two operand sets alternate
-      V bfr[2][NTW], afr[2][4];
+      VB bfr[2][NTW];
+      VA afr[2][4];
       auto ld_step = [&](int sidx, int set) {
         const int tap = sidx >> 1, ks = sidx & 1;
 #pragma unroll
@@ -494,7 +437,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         // every operand of this k-step first (independent LDS reads in flight together), then the MFMAs
-        V bf[NTW], af[4];
+        VB bf[NTW];
+        VA af[4];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) bf[n] = M::load_bp(xcol + (n * 16 + off) * RS + ks * 32 * LES, PLANE);
 #pragma unroll
@@ -546,7 +490,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      V bf[NTW], af[4];
+      VB bf[NTW];
+      VA af[4];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) bf[n] = M::load_bp(xcol + (n * 16) * RS + ks * 32 * LES, PLANE);
 #pragma unroll
@@ -567,10 +512,10 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      V cb[NTW];
+      VB cb[NTW];
 #pragma unroll
       for (int n = 0; n < NTW; ++n) cb[n] = M::from_acc(v[2 * s][n], v[2 * s + 1][n]);
-      V af[4];
+      VA af[4];
 #pragma unroll
       for (int m = 0; m < 4; ++m) af[m] = M::load_a(wl + (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + m * 2 + s) * FS + lane * 16, FRAG_BYTES);
 #pragma unroll
@@ -628,8 +573,8 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
           float xr[4], o[4];
           if constexpr (SPLIT) {
             float lo4[4];
-            Mma<bf16>::load4(rowp + (16 * m + 4 * g) * LES, xr);
-            Mma<bf16>::load4(rowp + PLANE + (16 * m + 4 * g) * LES, lo4);
+            M::load4p(rowp + (16 * m + 4 * g) * LES, xr);
+            M::load4p(rowp + PLANE + (16 * m + 4 * g) * LES, lo4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) xr[r] += lo4[r];
           } else {
@@ -682,7 +627,9 @@ __global__ __launch_bounds__(NWAVES * 64) void mrf_kernel(const T* __restrict__ 
   MRF_TM();
   if (lane == 0 && mrf_dbg) {
     long long* d = mrf_dbg + ((size_t)(PASS - 1) * 65536 + ((size_t)(b * nwg + wg) * NWAVES + wid)) * 12;
-    for (int i = 0; i < 12; ++i) d[i] = i < ntm ? tmk[i] - tmk[0] : -1;
+    for (int i = 0; i < 10; ++i) d[i] = i < ntm ? tmk[i] - tmk[0] : -1;
+    d[10] = t_abs0;
+    d[11] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
 
@@ -764,12 +711,13 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
     (void)hipFuncSetAttribute((const void*)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set[stdm] = lds;
   }
-  hipLaunchKernelGGL(k1, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, nullptr, part5,
-                     nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
-  hipLaunchKernelGGL(k2, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
-  hipLaunchKernelGGL(k3, grid, block, lds, stream, (const T*)x, (T*)out, (const char*)packed, meta, part5, nullptr,
-                     part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps, (const T*)nullptr, (const char*)nullptr);
+  using ST = StT<T>;
+  hipLaunchKernelGGL(k1, grid, block, lds, stream, (const ST*)x, (ST*)out, (const char*)packed, meta, nullptr, part5,
+                     nullptr, nullptr, nullptr, 1.f, Tn, nwg, nit, eps, (const ST*)nullptr, (const char*)nullptr);
+  hipLaunchKernelGGL(k2, grid, block, lds, stream, (const ST*)x, (ST*)out, (const char*)packed, meta, part5, nullptr,
+                     nullptr, part8, nullptr, 1.f, Tn, nwg, nit, eps, (const ST*)nullptr, (const char*)nullptr);
+  hipLaunchKernelGGL(k3, grid, block, lds, stream, (const ST*)x, (ST*)out, (const char*)packed, meta, part5, nullptr,
+                     part8, nullptr, mask, mask_scale, Tn, nwg, nit, eps, (const ST*)nullptr, (const char*)nullptr);
 #ifdef MV_MRF_TIMING
   if (++calls == 20) {
     hipStreamSynchronize(stream);
@@ -792,9 +740,9 @@ static int mrf_launch(const void* x, void* out, const void* packed, const MrfMet
 static inline size_t mrf_act_bytes(int B, int Tn, size_t es) { return (((size_t)B * Tn * MRF_C * es) + 255) / 256 * 256; }
 
 template <typename T, int NWAVES, int NTW, int PASS>
-static void mrf_chain_pass(bool stdm, dim3 grid, size_t lds, hipStream_t stream, const T* x, T* out, const char* packed,
+static void mrf_chain_pass(bool stdm, dim3 grid, size_t lds, hipStream_t stream, const StT<T>* x, StT<T>* out, const char* packed,
                            const MrfMeta& meta, const float* p5, float* p5o, const float* p8, float* p8o, int Tn, int nwg, int nit,
-                           float eps, const T* fprev, const char* packed_prev) {
+                           float eps, const StT<T>* fprev, const char* packed_prev) {
   auto k = stdm ? mrf_kernel<T, NWAVES, NTW, PASS, true> : mrf_kernel<T, NWAVES, NTW, PASS, false>;
   static size_t lds_set[2] = {0, 0};
   if (lds > lds_set[stdm]) {
@@ -838,9 +786,10 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
   const size_t lds = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS + MRF_TAB_FLOATS * 4 + (32 + 16) * 4 +
                      (size_t)NWAVES * 32 * 4 + tile_rows * RS;
   if (lds > 160 * 1024 || hmax > MRF_HMAX) return MV_ERR_UNSUPPORTED;
-  const size_t act = mrf_act_bytes(B, Tn, sizeof(T));
-  T* fbuf = reinterpret_cast<T*>(ws);
-  T* xbuf[2] = {reinterpret_cast<T*>(ws + act), reinterpret_cast<T*>(ws + 2 * act)};
+  using ST = StT<T>;
+  const size_t act = mrf_act_bytes(B, Tn, sizeof(ST));
+  ST* fbuf = reinterpret_cast<ST*>(ws);
+  ST* xbuf[2] = {reinterpret_cast<ST*>(ws + act), reinterpret_cast<ST*>(ws + 2 * act)};
   float* part5 = reinterpret_cast<float*>(ws + 3 * act);
   float* part8 = part5 + (size_t)B * nwg * 32;
   const dim3 grid(nwg, B);
@@ -852,19 +801,24 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
   static int wide_env = -1;
   if (wide_env < 0) { const char* e = getenv("MV_MRF_WIDE_STATS"); wide_env = e ? atoi(e) : 1; }   // bit 0: pass 1, bit 1: pass A
   const bool wide = WIDE_OK && wide_env && nit >= 2 && nit % 2 == 0 && lds_wide <= 160 * 1024 && Tn % (NWAVES * 32) == 0;
-  const T* xi = (const T*)x;                         // x_i: the input of block i
+#ifdef MV_MRF_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 6 * 65536 * 12 * 8); hipMemset(dbg, 0xff, 6 * 65536 * 12 * 8); hipMemcpyToSymbol(HIP_SYMBOL(mrf_dbg), &dbg, sizeof(dbg)); }
+#endif
+  const ST* xi = (const ST*)x;                       // x_i: the input of block i
   for (int i = 0; i < nblocks; ++i) {
     const bool stdm = mrf_meta_is_std(metas[i]);
     const char* pk = (const char*)packed[i];
     if (i == 0) {
       if (wide && (wide_env & 1))
-        mrf_chain_pass<T, NWAVES, (WIDE_OK ? 2 : NTW), 1>(stdm, grid, lds_wide, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr,
+        mrf_chain_pass<T, NWAVES, (WIDE_OK ? 2 : NTW), 1>(stdm, grid, lds_wide, stream, xi, (ST*)nullptr, pk, metas[i], nullptr, part5, nullptr,
                                                           nullptr, Tn, nwg, nit / 2, eps, nullptr, nullptr);
       else
-        mrf_chain_pass<T, NWAVES, NTW, 1>(stdm, grid, lds, stream, xi, (T*)nullptr, pk, metas[i], nullptr, part5, nullptr, nullptr, Tn, nwg,
+        mrf_chain_pass<T, NWAVES, NTW, 1>(stdm, grid, lds, stream, xi, (ST*)nullptr, pk, metas[i], nullptr, part5, nullptr, nullptr, Tn, nwg,
                                           nit, eps, nullptr, nullptr);
     } else {
-      T* xn = xbuf[i & 1];                           // pass A: x_i = GN8_{i-1}(f_{i-1}) + x_{i-1}, written once; statistics of v_i
+      ST* xn = xbuf[i & 1];                          // pass A: x_i = GN8_{i-1}(f_{i-1}) + x_{i-1}, written once; statistics of v_i
       if (wide && (wide_env & 2))      // (pass A at 32-step tiles needs 256 VGPRs + spills: 50 vs 43 us - off by default)
         mrf_chain_pass<T, NWAVES, (WIDE_OK ? 2 : NTW), 4>(stdm, grid, lds_wide, stream, xi, xn, pk, metas[i], nullptr, part5, part8, nullptr,
                                                           Tn, nwg, nit / 2, eps, fbuf, (const char*)packed[i - 1]);
@@ -877,6 +831,33 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
     mrf_chain_pass<T, NWAVES, NTW, 5>(stdm, grid, lds, stream, xi, fbuf, pk, metas[i], part5, nullptr, nullptr, part8, Tn, nwg, nit, eps,
                                       nullptr, nullptr);
   }
+#ifdef MV_MRF_TIMING
+  {
+    const char* e = getenv("MV_MRF_TIMING_CALL");
+    if (++calls == (e ? atoi(e) : 30)) {
+      hipStreamSynchronize(stream);
+      static long long hbuf[6 * 65536 * 12];
+      hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+      for (int ps = 0; ps < 6; ++ps) {
+        double avg[10] = {0}; int cnt[10] = {0};
+        long long tmin = -1, tmax = -1, smax = -1;
+        for (int w = 0; w < 65536; ++w) {
+          const long long* d = hbuf + ((size_t)ps * 65536 + w) * 12;
+          if (d[0] < 0) continue;
+          for (int k = 0; k < 10; ++k) if (d[k] >= 0) { avg[k] += (double)d[k]; cnt[k]++; }
+          if (tmin < 0 || d[10] < tmin) tmin = d[10];
+          if (d[10] > smax) smax = d[10];
+          if (d[11] > tmax) tmax = d[11];
+        }
+        if (!cnt[0]) continue;
+        fprintf(stderr, "[mrf chain timing] pass %d nwg %d nit %d waves %d: span %.2f us (last start +%.2f us) marks:", ps + 1, nwg, nit, cnt[0],
+                (tmax - tmin) / 100.0, (smax - tmin) / 100.0);
+        for (int k = 0; k < 10; ++k) if (cnt[k]) fprintf(stderr, " %.0f", avg[k] / cnt[k]);
+        fprintf(stderr, "\n");
+      }
+    }
+  }
+#endif
   if (ab_out) {
     constexpr size_t WB = (size_t)(MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FS;
     const float* tabp = reinterpret_cast<const float*>((const char*)packed[nblocks - 1] + WB);
@@ -888,7 +869,7 @@ static int mrf_chain_launch(const void* x, void* out, const void* const* packed,
   }
   MrfMeta mf = metas[nblocks - 1];
   mf.halo = 0;                                       // pass F touches this wave's own rows only
-  mrf_chain_pass<T, NWAVES, NTW, 6>(true, grid, lds, stream, xi, (T*)out, (const char*)packed[nblocks - 1], mf, nullptr, nullptr, part8,
+  mrf_chain_pass<T, NWAVES, NTW, 6>(true, grid, lds, stream, xi, (ST*)out, (const char*)packed[nblocks - 1], mf, nullptr, nullptr, part8,
                                     nullptr, Tn, nwg, nit, eps, fbuf, (const char*)packed[nblocks - 1]);
   return MV_OK;
 }
@@ -901,13 +882,30 @@ extern "C" size_t mv_mrf_packed_bytes(int dtype) {
   switch (dtype) {
     case MV_F32: return mrf_packed_bytes<float>();
     case MV_BF16: return mrf_packed_bytes<bf16>();
-    case MV_F16: return mrf_packed_bytes<f16>();
+    case MV_F16: case MV_F32_W16: return mrf_packed_bytes<f16>();
     default: return 0;
   }
 }
 
 // tile geometry per storage type: bf16/f16: 8 waves x 64 steps; fp32 (split operands, 2x LDS): 8 x 16 or 4 x 32 steps
-static inline int mrf_tile_t(int dtype) { return dtype == MV_F32 ? 8 * 1 * 16 : 8 * 4 * 16; }
+static inline bool mrf_fp32_storage(int dtype) { return dtype == MV_F32 || dtype == MV_F32_W16; }
+static inline int mrf_tile_t(int dtype) { return dtype == MV_F32_W16 ? 4 * 1 * 16 : dtype == MV_F32 ? 8 * 1 * 16 : 8 * 4 * 16; }
+// f32w16 wave tile: 16 or 32 steps (MV_MRF_W16_NTW=1|2; the single-f16 weight image is 48 KB, so a 256-step shared tile fits)
+static inline int mrf_w16_stream() {     // MV_MRF_STREAM=0: the tile form for MV_F32_W16 (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MV_MRF_STREAM"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static inline int mrf_w16_nw() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MV_MRF_W16_NW"); v = (e && atoi(e) == 4) ? 4 : (e && atoi(e) == 16) ? 16 : 8; }
+  return v;
+}
+static inline int mrf_w16_ntw() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MV_MRF_W16_NTW"); v = (e && atoi(e) == 1) ? 1 : 2; }
+  return v;
+}
 
 extern "C" size_t mv_mrf_workspace_bytes(int B, int T_, int dtype) {
   const int ntiles = cdiv(T_, mrf_tile_t(dtype));   // upper bound on workgroups per sample
@@ -936,6 +934,7 @@ extern "C" int mv_mrf_pack(const mv_mrf_params* params, int param_dtype, const i
   MV_CHECK_ARG(params && dilations && packed && lora_rank > 0);
   MrfMeta meta;
   if (!mrf_make_meta(dilations, &meta)) return MV_ERR_UNSUPPORTED;
+  if (dtype == MV_F32_W16) return mrf_pack_dispatch<f16>(params, meta, packed, lora_rank, param_dtype, (hipStream_t)stream);
   MV_DISPATCH(dtype, return mrf_pack_dispatch<T>(params, meta, packed, lora_rank, param_dtype, (hipStream_t)stream));
   return MV_OK;
 }
@@ -966,7 +965,7 @@ extern "C" int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed,
 }
 
 extern "C" size_t mv_mrf_chain_workspace_bytes(int B, int T_, int dtype) {
-  const size_t es = dtype == MV_F32 ? 4 : 2;
+  const size_t es = mrf_fp32_storage(dtype) ? 4 : 2;
   return 3 * mrf_act_bytes(B, T_, es) + (mv_mrf_workspace_bytes(B, T_, dtype) + 255) / 256 * 256 + (size_t)B * 128 * sizeof(float);
 }
 
@@ -984,19 +983,33 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
   }
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
-  const size_t es = dtype == MV_F32 ? 4 : 2;
+  const size_t es = mrf_fp32_storage(dtype) ? 4 : 2;
   float* ab = reinterpret_cast<float*>(ws + 3 * mrf_act_bytes(B, T_, es) + (mv_mrf_workspace_bytes(B, T_, dtype) + 255) / 256 * 256);
   const void* fl = nullptr;
   const void* xl_ = nullptr;
   int rc;
-  const bool fold = mvi_conv_out_affine_takes_partials(dtype, ks);     // the output conv forms the last block's affine itself: one launch less
-  const float* p8 = nullptr; const float* tb8 = nullptr; int nwg8 = 0;
+  const int cdt = dtype == MV_F32_W16 ? MV_F32 : dtype;                // the output conv sees fp32 rows either way
+  const bool fold = mvi_conv_out_affine_takes_partials(cdt, ks);     // the output conv forms the last block's affine itself: one launch less
+  const float* p8 = nullptr; const float* tb8 = nullptr; int nwg8 = 0, x_pair = 0;
+  bool all_std = true;
+  for (int i = 0; i < nblocks; ++i) all_std = all_std && mrf_meta_is_std(metas[i]);
   switch (dtype) {
     case MV_F32:
       rc = mrf_chain_launch<float, 8, 1>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8);
       if (rc == MV_ERR_UNSUPPORTED)
         rc = mrf_chain_launch<float, 4, 2>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8);
       break;
+    case MV_F32_W16: {
+      if (mrf_w16_stream() && fold && all_std) {     // streaming form (mrf_stream.hip)
+        rc = mvi_mrf_chain_stream(x, nullptr, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &x_pair, &p8, &tb8, &nwg8);
+        if (rc != MV_ERR_UNSUPPORTED) break;
+      }
+      const int cfg = mrf_w16_nw() * 10 + mrf_w16_ntw();
+#define MV_W16_CHAIN(NW_, NTW_) mrf_chain_launch<f32w16, NW_, NTW_>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8)
+      rc = cfg == 82 ? MV_W16_CHAIN(8, 2) : cfg == 81 ? MV_W16_CHAIN(8, 1) : cfg == 42 ? MV_W16_CHAIN(4, 2) : cfg == 161 ? MV_W16_CHAIN(16, 1) : MV_W16_CHAIN(4, 1);
+#undef MV_W16_CHAIN
+      break;
+    }
     case MV_BF16: rc = mrf_chain_launch<bf16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
     case MV_F16: rc = mrf_chain_launch<f16, 8, 4>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_); break;
     default: return MV_ERR_DTYPE;
@@ -1004,7 +1017,7 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   // conv_packed = mv_conv_out_pack_all image: the fp32 [ks][64] weights come first
-  rc = mvi_conv_out_affine(fl, xl_, ab, (const float*)conv_packed, conv_bias, wave, B, T_, MRF_C, ks, ks / 2, act, dtype, st, p8, tb8, nwg8, eps);
+  rc = mvi_conv_out_affine(fl, xl_, ab, (const float*)conv_packed, conv_bias, wave, B, T_, MRF_C, ks, ks / 2, act, cdt, st, p8, tb8, nwg8, eps, x_pair);
   if (rc != MV_OK) return rc;
   MV_LAUNCH_CHECK();
   return MV_OK;
@@ -1027,6 +1040,20 @@ extern "C" int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* 
       rc = mrf_chain_launch<float, 8, 1>(x, out, packed, metas, nblocks, ws, B, T_, eps, st);
       if (rc == MV_ERR_UNSUPPORTED) rc = mrf_chain_launch<float, 4, 2>(x, out, packed, metas, nblocks, ws, B, T_, eps, st);
       break;
+    case MV_F32_W16: {
+      bool all_std = true;
+      for (int i = 0; i < nblocks; ++i) all_std = all_std && mrf_meta_is_std(metas[i]);
+      if (mrf_w16_stream() && all_std) {
+        const void* fl = nullptr; const void* xl_ = nullptr; int xp = 0, nw = 0; const float* p8 = nullptr; const float* tb = nullptr;
+        rc = mvi_mrf_chain_stream(x, out, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &xp, &p8, &tb, &nw);
+        if (rc != MV_ERR_UNSUPPORTED) break;
+      }
+      const int cfg = mrf_w16_nw() * 10 + mrf_w16_ntw();
+#define MV_W16_CHAIN(NW_, NTW_) mrf_chain_launch<f32w16, NW_, NTW_>(x, out, packed, metas, nblocks, ws, B, T_, eps, st)
+      rc = cfg == 82 ? MV_W16_CHAIN(8, 2) : cfg == 81 ? MV_W16_CHAIN(8, 1) : cfg == 42 ? MV_W16_CHAIN(4, 2) : cfg == 161 ? MV_W16_CHAIN(16, 1) : MV_W16_CHAIN(4, 1);
+#undef MV_W16_CHAIN
+      break;
+    }
     case MV_BF16: rc = mrf_chain_launch<bf16, 8, 4>(x, out, packed, metas, nblocks, ws, B, T_, eps, st); break;
     case MV_F16: rc = mrf_chain_launch<f16, 8, 4>(x, out, packed, metas, nblocks, ws, B, T_, eps, st); break;
     default: return MV_ERR_DTYPE;

@@ -89,7 +89,7 @@ class MrfFused:
         ws = self._ws.get(key)
         if ws is None:
             ws = torch.empty(wsb, dtype=torch.uint8, device=x_cl.device)
-            self._ws = {key: ws}
+            self._ws[key] = ws                     # never evicted: a captured HIP graph may have baked this pointer in
         out = torch.empty_like(x_cl)
         dil = _INT3(*self.blk.dilations)
         N.call("mv_mrf_block_fwd_cl", c_void_p(x_cl.data_ptr()), c_void_p(out.data_ptr()), c_void_p(packed.data_ptr()),
@@ -105,13 +105,20 @@ class MrfChain:
         self.mrfs = list(mrfs)
         self._ws = {}
 
-    def forward_cl(self, x_cl, nblocks=None):
+    def _mode(self, x_cl, w16):
+        """(mv_dtype code, dtype of the packed weight image): w16 = fp32 storage with single-f16 weights (MV_F32_W16)."""
+        if w16:
+            assert x_cl.dtype == torch.float32
+            return N.MV_F32_W16, torch.float16
+        return ops._dt(x_cl), x_cl.dtype
+
+    def forward_cl(self, x_cl, nblocks=None, w16=False):
         """x_cl [B, T, 64] contiguous -> output of block nblocks-1 (default: the last), a new tensor."""
         n = len(self.mrfs) if nblocks is None else nblocks
         B, T, C = x_cl.shape
         assert C == 64 and x_cl.is_contiguous() and 1 <= n <= len(self.mrfs)
-        dt = ops._dt(x_cl)
-        packs = [m.packed(x_cl.dtype, x_cl.device) for m in self.mrfs[:n]]
+        dt, pdt = self._mode(x_cl, w16)
+        packs = [m.packed(pdt, x_cl.device) for m in self.mrfs[:n]]
         ptrs = (c_void_p * n)(*[p.data_ptr() for p in packs])
         dil = (ctypes.c_int * (3 * n))(*[d for m in self.mrfs[:n] for d in m.blk.dilations])
         wsb = N.lib().mv_mrf_chain_workspace_bytes(B, T, dt)
@@ -119,7 +126,7 @@ class MrfChain:
         ws = self._ws.get(key)
         if ws is None:
             ws = torch.empty(wsb + 256, dtype=torch.uint8, device=x_cl.device)
-            self._ws = {key: ws}
+            self._ws[key] = ws                     # never evicted: a captured HIP graph may have baked this pointer in
         base = (ws.data_ptr() + 255) // 256 * 256
         out = torch.empty_like(x_cl)
         eps = float(self.mrfs[0].blk.norm.eps)
@@ -127,13 +134,13 @@ class MrfChain:
                ops._stream())
         return out
 
-    def forward_out_cl(self, x_cl, conv_packed, conv_bias, ks, act):
+    def forward_out_cl(self, x_cl, conv_packed, conv_bias, ks, act, w16=False):
         """Chain + output projection + activation in one call (mv_mrf_chain_out_fwd_cl): x_cl [B, T, 64] -> wave [B, 1, T]."""
         n = len(self.mrfs)
         B, T, C = x_cl.shape
         assert C == 64 and x_cl.is_contiguous()
-        dt = ops._dt(x_cl)
-        packs = [m.packed(x_cl.dtype, x_cl.device) for m in self.mrfs]
+        dt, pdt = self._mode(x_cl, w16)
+        packs = [m.packed(pdt, x_cl.device) for m in self.mrfs]
         ptrs = (c_void_p * n)(*[p.data_ptr() for p in packs])
         dil = (ctypes.c_int * (3 * n))(*[d for m in self.mrfs for d in m.blk.dilations])
         wsb = N.lib().mv_mrf_chain_workspace_bytes(B, T, dt)
@@ -141,7 +148,7 @@ class MrfChain:
         ws = self._ws.get(key)
         if ws is None:
             ws = torch.empty(wsb + 256, dtype=torch.uint8, device=x_cl.device)
-            self._ws = {key: ws}
+            self._ws[key] = ws                     # never evicted: a captured HIP graph may have baked this pointer in
         base = (ws.data_ptr() + 255) // 256 * 256
         wave = torch.empty(B, 1, T, device=x_cl.device, dtype=x_cl.dtype)
         N.call("mv_mrf_chain_out_fwd_cl", c_void_p(x_cl.data_ptr()), c_void_p(wave.data_ptr()), ptrs, dil, n, c_void_p(base),
@@ -421,15 +428,16 @@ class GeneratorFused:
         # at C2.  16-bit storage keeps the per-block kernels (the chain's extra stream transfer costs more than the MFMAs it saves:
         # 174 vs 166 us).  The per-stage outputs, when asked for, are chains over the first i+1 blocks.
         use_chain = self.chain is not None and x.dtype == torch.float32
+        w16 = bool(getattr(g, "_mv_mrf_w16", False)) and mixed is not None
         if use_chain and not return_stages:
             wt, bias = self.out_weights(mel.device)
-            return self.chain.forward_out_cl(x, wt, bias, g.output_proj.kernel_size[0], N.ACT_TANH)
+            return self.chain.forward_out_cl(x, wt, bias, g.output_proj.kernel_size[0], N.ACT_TANH, w16=w16)
         if use_chain:
             x_in = x
             if return_stages:
                 for i in range(len(self.mrfs) - 1):
-                    st[f"mrf{i}"] = self.chain.forward_cl(x_in, i + 1)
-            x = self.chain.forward_cl(x_in)
+                    st[f"mrf{i}"] = self.chain.forward_cl(x_in, i + 1, w16=w16)
+            x = self.chain.forward_cl(x_in, w16=w16)
             if return_stages:
                 st[f"mrf{len(self.mrfs) - 1}"] = x
         else:

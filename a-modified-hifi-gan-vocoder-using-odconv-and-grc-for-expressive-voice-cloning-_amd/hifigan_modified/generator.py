@@ -101,12 +101,18 @@ class ModifiedHiFiGANGenerator(nn.Module):
         for m in [self.input_proj] + [l[0] for l in self.upsample_layers]:
             yield from m.unused_parameters()
 
-    def set_mixed_precision(self, through="up1", dtype=torch.float16):
+    def set_mixed_precision(self, through="up1", dtype=torch.float16, mrf_weights=None):
         """Inference-only storage mix for an fp32-storage model (not in the reference): the stages up to and including `through`
         ("input_proj", "up0", "up1", ...; None switches the mix off) run in `dtype` storage, everything behind - the last upsamplers,
         the three MultiReceptiveFieldBlocks, the output conv - in fp32 storage with split bf16 MFMA operands.  The early stages feed
         a 1e3x gain chain, but their rounding enters once; tools/error_budget.py puts fp16 through up1 at 5.9e-4 waveform rel-L2 on the
-        22 kHz generator (north_star: 1e-3) and above 1e-3 on the 48 kHz one - DESIGN.md section 5.  Returns self."""
+        22 kHz generator (north_star: 1e-3) and above 1e-3 on the 48 kHz one - DESIGN.md section 5.
+        mrf_weights="fp16": the three MultiReceptiveFieldBlocks keep fp32 storage and hi + lo (f16) activation operands but use their
+        weights as single f16 values - two MFMA products per MAC instead of three (MV_F32_W16; +1.1e-4 in quadrature at 22 kHz,
+        out of tolerance at 48 kHz).  Returns self."""
+        if mrf_weights not in (None, "fp16"):
+            raise ValueError("mrf_weights must be None or 'fp16'")
+        object.__setattr__(self, "_mv_mrf_w16", mrf_weights == "fp16" and through is not None)
         if through is None:
             mixed = None
         else:

@@ -27,7 +27,11 @@
 extern "C" {
 #endif
 
-typedef enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2 } mv_dtype;
+typedef enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2,
+               /* operand mode of the mv_mrf_* entry points only: fp32 storage, every MFMA activation operand a hi + lo f16 pair, the
+                * weights a single f16 (pack with this code as well: the image is the MV_F16 one) - two products per MAC instead of
+                * MV_F32's three (hi + lo bf16 on both sides).  Not a storage type: every other entry point rejects it. */
+               MV_F32_W16 = 3 } mv_dtype;
 typedef enum { MV_ACT_NONE = 0, MV_ACT_LRELU = 1, MV_ACT_TANH = 2, MV_ACT_SILU = 3 } mv_act;
 
 #define MV_OK 0

@@ -39,8 +39,9 @@ STAGES = ["mel", "input_proj", "up0", "up1", "up2", "up3", "mrf0", "mrf1", "mrf2
 LAYERS = ["input_proj", "up0", "up1", "up2", "up3", "mrf0", "mrf1", "mrf2", "out"]
 
 
-def forward(mel, sd, spk, emo, ups_f, act, wgt, cmode, kloop_layers=("input_proj", "up0"), opmode=None):
-    """act[stage] = storage/operand mode of that stage's OUTPUT; wgt[layer] = weight mode; cmode[i] = mode of MRF i's concat."""
+def forward(mel, sd, spk, emo, ups_f, act, wgt, cmode, kloop_layers=("input_proj", "up0"), opmode=None, fmode=None):
+    """act[stage] = storage/operand mode of that stage's OUTPUT; wgt[layer] = weight mode (an MRF layer may give a dict
+    {conv, res, fus}); cmode[i] = mode of MRF i's concat; fmode = storage mode of the chain's pre-GroupNorm fusion output f."""
     ups, mrfs, cur = O.generator_channel_plan(512, ups_f, 4, ((1, 3, 5),) * 3)
 
     def odconv(x, prefix, name, transposed, **kw):
@@ -65,6 +66,7 @@ def forward(mel, sd, spk, emo, ups_f, act, wgt, cmode, kloop_layers=("input_proj
     for i, (_, _, dil) in enumerate(mrfs):
         pre = f"mrf_blocks.{i}."
         wm = wgt[f"mrf{i}"]
+        wmc, wmr, wmf = (wm["conv"], wm["res"], wm["fus"]) if isinstance(wm, dict) else (wm, wm, wm)
         xs = x                                   # as stored (residual path reads this)
         if opmode is not None:                   # MFMA operand view of the stored stream
             x = q(xs, opmode)
@@ -84,13 +86,15 @@ def forward(mel, sd, spk, emo, ups_f, act, wgt, cmode, kloop_layers=("input_proj
             Pw = sd[p + "output_projection.weight"][:, :, 0]
             Weff = torch.einsum("oq,qck->ock", Pw, Wd)
             beff = Pw @ sd[p + "conv.bias"] + sd[p + "output_projection.bias"]
-            v = F.conv1d(x, q(Weff, wm), beff, padding=d, dilation=d)
+            v = F.conv1d(x, q(Weff, wmc), beff, padding=d, dilation=d)
             w = O.group_norm(v, O.norm_groups_for(out_ch), sd[p + "norm.weight"], sd[p + "norm.bias"])
             a = O.silu(w)
-            res = F.conv1d(x, q(sd[p + "residual_proj.weight"], wm), sd[p + "residual_proj.bias"])
+            res = F.conv1d(x, q(sd[p + "residual_proj.weight"], wmr), sd[p + "residual_proj.bias"])
             branches.append(a + res)
         c = q(torch.cat(branches, 1), cmode[i])
-        f_ = F.conv1d(c, q(sd[pre + "fusion.weight"], wm), sd[pre + "fusion.bias"])
+        f_ = F.conv1d(c, q(sd[pre + "fusion.weight"], wmf), sd[pre + "fusion.bias"])
+        if fmode is not None:
+            f_ = q(f_, fmode)
         n = O.group_norm(f_, O.norm_groups_for(f_.shape[1]), sd[pre + "norm.weight"], sd[pre + "norm.bias"])
         x = q(n + xs, act[f"mrf{i}"])
     Wo = sd["output_proj.weight"]
