@@ -112,8 +112,9 @@ class MrfChain:
             return N.MV_F32_W16, torch.float16
         return ops._dt(x_cl), x_cl.dtype
 
-    def forward_cl(self, x_cl, nblocks=None, w16=False):
-        """x_cl [B, T, 64] contiguous -> output of block nblocks-1 (default: the last), a new tensor."""
+    def forward_cl(self, x_cl, nblocks=None, w16=False, materialize=True):
+        """x_cl [B, T, 64] contiguous -> output of block nblocks-1 (default: the last), a new tensor.  materialize=False: the
+        chain's passes only (what the generator runs in front of its fused output conv) - returns None; bench.py times that."""
         n = len(self.mrfs) if nblocks is None else nblocks
         B, T, C = x_cl.shape
         assert C == 64 and x_cl.is_contiguous() and 1 <= n <= len(self.mrfs)
@@ -128,10 +129,10 @@ class MrfChain:
             ws = torch.empty(wsb + 256, dtype=torch.uint8, device=x_cl.device)
             self._ws[key] = ws                     # never evicted: a captured HIP graph may have baked this pointer in
         base = (ws.data_ptr() + 255) // 256 * 256
-        out = torch.empty_like(x_cl)
+        out = torch.empty_like(x_cl) if materialize else None
         eps = float(self.mrfs[0].blk.norm.eps)
-        N.call("mv_mrf_chain_fwd_cl", c_void_p(x_cl.data_ptr()), c_void_p(out.data_ptr()), ptrs, dil, n, c_void_p(base), B, T, eps, dt,
-               ops._stream())
+        N.call("mv_mrf_chain_fwd_cl", c_void_p(x_cl.data_ptr()), None if out is None else c_void_p(out.data_ptr()), ptrs, dil, n,
+               c_void_p(base), B, T, eps, dt, ops._stream())
         return out
 
     def forward_out_cl(self, x_cl, conv_packed, conv_bias, ks, act, w16=False):

@@ -161,6 +161,7 @@ def graph_time_ms(run, inner=20, outer=5):
 PARITY_TOL = 1e-3           # north_star: waveform rel-L2 vs the reference CPU path
 DT = {"bf16": "bfloat16", "fp16": "float16", "fp32": "float32", "mixed": "float32"}
 MIXED_THROUGH = "up1"       # --dtype mixed: fp16 storage up to and including this stage, fp32 storage (split operands) behind it
+MIXED_MRF_W16 = True        # ... and the three MRF blocks with two-product operands (hi + lo f16 activations x single f16 weights)
 
 
 def spawn_ranks(n):
@@ -202,11 +203,12 @@ def _pmc_summaries(dtype_tag, files=None):
     return out
 
 
-def pmc_traffic(kernel_substr, dtype_tag, per_launch_of=None, files=None):
+def pmc_traffic(kernel_substr, dtype_tag, per_launch_of=None, files=None, nblocks=1):
     """HBM bytes from the committed PMC summary, or None when no summary matches this dtype / these kernel sources.
     Sum over the kernels whose name contains `kernel_substr` of (fetch + write bytes); divided by the launch count of the kernel
     whose name contains `per_launch_of` (e.g. one MRF block = all mrf_kernel passes / launches of its once-per-block pass),
-    or - without it - the plain per-launch average of the single matching kernel."""
+    or - without it - the plain per-launch average of the single matching kernel.  nblocks: the marker kernel runs once per chain
+    of that many blocks (the streaming chain's F0 pass)."""
     best = None
     for f, j in _pmc_summaries(dtype_tag, files):
         tot, marker = 0.0, 0
@@ -217,7 +219,7 @@ def pmc_traffic(kernel_substr, dtype_tag, per_launch_of=None, files=None):
             if per_launch_of and kernel_substr in name and per_launch_of in name:
                 marker += k["launches"]
         if tot and (marker or not per_launch_of):
-            best = {"bytes": int(tot / marker) if per_launch_of else int(tot), "file": "profiles/" + f}
+            best = {"bytes": int(tot / marker / nblocks) if per_launch_of else int(tot), "file": "profiles/" + f}
     return best
 
 
@@ -291,16 +293,17 @@ def main():
     spk32 = torch.randn(B, 192, device=dev)
     emo32 = torch.randn(B, 384, device=dev)
 
-    def build(dt, mixed=False):
+    def build(dt, mixed=False, w16=MIXED_MRF_W16):
         g = H.ModifiedHiFiGANGenerator()
         g.load_state_dict(sd_cpu)
         g = g.to(dev).to(dt).train(False)
         if mixed:
-            g.set_mixed_precision(MIXED_THROUGH, torch.float16)
+            g.set_mixed_precision(MIXED_THROUGH, torch.float16, mrf_weights="fp16" if w16 else None)
         return g, mel32.to(dt), spk32.to(dt), emo32.to(dt)
 
     gen, mel, spk, emo = build(dtype, mixed=(args.dtype == "mixed"))
-    mrf_tag = "fp32" if args.dtype == "mixed" else args.dtype     # the MRF blocks of the mixed mode are the fp32-storage chain
+    # the MRF blocks of the mixed mode are the fp32-storage chain, with two-product operands in its streaming form (mrf_stream.hip)
+    mrf_tag = ("fp32w16" if MIXED_MRF_W16 else "fp32") if args.dtype == "mixed" else args.dtype
 
     # waveforms of 2 clips of this very configuration, checked against the oracle in the CPU leg (cpu_baseline)
     checks = {}
@@ -351,36 +354,46 @@ def main():
     from hifigan_modified.fused import generator_fused_for
 
     def mrf_roofline(g, m, s, e, tag):
-        """One MRF block as the generator really runs it: fp32 storage = a third of the three-block chain (mv_mrf_chain_fwd_cl:
-        PASS 1 + 3 x PASS 5 + 2 x PASS 4 + the materialising PASS 6), 16-bit storage = the per-block kernel (3 pass launches)."""
+        """One MRF block as the generator really runs it.  fp32 storage: a third of the three-block chain's passes, timed WITHOUT a
+        materialising pass (the generator forms the last block's output inside its output conv) - tile form (`fp32`: PASS 1 +
+        3 x PASS 5 + 2 x PASS 4 of mv::mrf_kernel<float>) or streaming form (`fp32w16`: V0 + F0 + 2 x (A + F) of
+        mv::mrf_stream_kernel).  16-bit storage: the per-block kernel (3 pass launches)."""
         fzz = generator_fused_for(g)
+        w16 = tag == "fp32w16"
         with torch.no_grad():
             st_ = g(m, s, e, return_stages=True)
             x_cl = ops.nct_to_ntc(st_["up%d" % (len(g.upsample_layers) - 1)])
             nblk, chained = 1, False
             if fzz is not None and fzz.chain is not None and x_cl.dtype == torch.float32:
-                run, nblk, chained = (lambda: fzz.chain.forward_cl(x_cl)), len(fzz.mrfs), True
+                run, nblk, chained = (lambda: fzz.chain.forward_cl(x_cl, w16=w16, materialize=False)), len(fzz.mrfs), True
             elif fzz is not None:
                 run = lambda: fzz.mrfs[0].forward_cl(x_cl)
             else:
                 run = lambda: g.mrf_blocks[0](st_["up3"])
             ms = graph_time_ms(run) / nblk
         elt = x_cl.element_size()
-        alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block, once (SURVEY 8(d): 64 ch in + 64 ch out per sample)
+        alg_bytes = 2 * x_cl.numel() * elt          # in + out of the block once, at the storage width
+        alg_8d = 2 * x_cl.numel() * 2               # SURVEY 8(d)'s figure: 256 B per output sample (64 ch in + 64 ch out x 2 B)
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        # one block = every mrf_kernel pass of this storage type / launches of the pass that runs once per block (chain: 5, else 3)
-        cname = {"fp32": "mrf_kernel<float", "bf16": "mrf_kernel<__hip_bfloat16", "fp16": "mrf_kernel<_Float16"}[tag]
-        tr = pmc_traffic(cname, tag, per_launch_of=(", 5, " if chained else ", 3, "),
-                         files=("mrf_fused.hip", "mfma.h", "common.h")) if (B == 32 and Tm == 32) else None
-        how = ("three-block chain / 3: 7 pass launches per 3 blocks, GroupNorm(8,64) deferred into the next block's load"
+        # one block = every pass of this storage type / launches of the pass that runs once per block
+        cname = {"fp32": "mrf_kernel<float", "fp32w16": "mrf_stream_kernel", "bf16": "mrf_kernel<__hip_bfloat16", "fp16": "mrf_kernel<_Float16"}[tag]
+        per = "mrf_stream_kernel<1," if w16 else (", 5, " if chained else ", 3, ")
+        tr = pmc_traffic(cname, tag, per_launch_of=per, nblocks=(nblk if w16 else 1),
+                         files=(("mrf_stream.hip", "mrf_common.h") if w16 else ("mrf_fused.hip",)) + ("mfma.h", "common.h")) if (B == 32 and Tm == 32) else None
+        how = ("streaming three-block chain / 3: 6 pass launches per 3 blocks (V0, F0, 2 x (A, F)), GroupNorm(8,64) deferred into the next "
+               "block's pass A, residual stream between blocks as pre-split f16 hi/lo rows read by LDS-DMA" if w16 else
+               "three-block chain / 3: 6 pass launches per 3 blocks, GroupNorm(8,64) deferred into the next block's load"
                if chained else "per-block kernel = 3 pass launches")
-        r = {"bound": "hbm", "kernel": "mv::mrf_kernel<%s> (fused MRF block; %s)" % (tag, how), "achieved": round(achieved, 1),
+        r = {"bound": "hbm", "kernel": "mv::%s> (fused MRF block; %s)" % (cname, how), "achieved": round(achieved, 1),
              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "frac_survey_8d": round(alg_8d / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "traffic": tr["bytes"] if tr else None, "traffic_source": tr["file"] if tr else None,
-             "alg_bytes_per_launch": alg_bytes, "ms_per_launch": round(ms, 4),
-             "note": "GroupNorm is global in T, so a block is several passes over the stream: per-block form 3 reads + 1 write, chain "
-                     "form 5 transfers per block; with split operands (fp32 storage) every product is 3 MFMAs and the block is "
-                     "matrix-pipe / LDS bound, not HBM bound (DESIGN.md section 4)"}
+             "alg_bytes_per_launch": alg_bytes, "alg_bytes_survey_8d": alg_8d, "ms_per_launch": round(ms, 4),
+             "note": "achieved / frac use the bytes of the storage type that meets north_star (fp32: 512 B per output sample); "
+                     "frac_survey_8d prices the same time against SURVEY 8(d)'s 2-byte figure (256 B per output sample).  GroupNorm is global "
+                     "in T, so a block is several passes over the stream: the chain moves 5 stream transfers per block (A: read f, read x, "
+                     "write x'; F: read x', write f), i.e. 2.5x the storage-width algorithmic bytes by construction; in-kernel marks put the "
+                     "passes at 3.9-5.4 TB/s of moved bytes (DESIGN.md section 4)"}
         return r, st_, fzz
 
     roof = od_roof = None
@@ -410,11 +423,14 @@ def main():
     modes = None
     if rank == 0 and world == 1 and not args.eager and not args.no_modes:
         modes = {}
-        for tag in ("bf16", "fp16", "fp32"):
-            if tag == args.dtype:
+        for tag in ("bf16", "fp16", "fp32", "mixed_3prod"):
+            if tag == args.dtype or (tag == "mixed_3prod" and not (args.dtype == "mixed" and MIXED_MRF_W16)):
                 continue
-            dt = getattr(torch, DT[tag])
-            g2, m2, s2, e2 = build(dt)
+            if tag == "mixed_3prod":     # round 2's headline mode: the same storage mix with three-product (hi + lo bf16) MRF operands
+                g2, m2, s2, e2 = build(torch.float32, mixed=True, w16=False)
+            else:
+                dt = getattr(torch, DT[tag])
+                g2, m2, s2, e2 = build(dt)
             with torch.no_grad():
                 checks["mode_" + tag] = (host(g2(m2[:2], s2[:2], e2[:2])), (host(m2[:2]), host(s2[:2]), host(e2[:2])))
             gv = GraphedVocoder(g2, m2, s2, e2)
@@ -470,15 +486,15 @@ def main():
             if not args.eager and hasattr(v3, "graphed"):
                 run_v3 = v3.graphed(mel_v3)
                 launch = "hipgraph"
-            for _ in range(3):
-                run_v3()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_v3 = 50
-            for _ in range(n_v3):
-                run_v3()
-            torch.cuda.synchronize()
-            el_v3 = time.perf_counter() - t1
+            # same protocol as the headline leg: this leg follows CPU-bound sections (idle clocks: the driver's box measured 2x the
+            # builder's figure with 3 warm replays): ~0.3 s of untimed replays, then the timed ones
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < 0.3:
+                for _ in range(20):
+                    run_v3()
+                torch.cuda.synchronize()
+            n_v3 = 200
+            el_v3 = timed_replays(run_v3, n_v3) * n_v3
         check_v3 = (w_v3.cpu(), mel_v3.cpu(), sd_v3)
         cfg_v3 = {"workload": "configs[0]: plain HiFi-GAN V3 generator, B=1 x 344 mel frames (4 s at 22.05 kHz), fp32",
                   "value": round(344 * n_v3 / el_v3, 1), "unit": "mel-frames/s", "ms_per_step": round(el_v3 / n_v3 * 1e3, 3), "dtype": "fp32",
@@ -604,12 +620,15 @@ def main():
 
     if rank == 0:
         frames = B * Tm * world * args.steps
-        precision = {"mixed": "fp16 storage and MFMA operands through %s (prologue, input_proj + FiLM, the first upsamplers), then fp32 storage with "
-                              "every MFMA operand split into hi + lo bf16 (3 products per MAC); fp32 accumulate throughout" % MIXED_THROUGH,
+        precision = {"mixed": "fp16 storage and MFMA operands through %s (prologue, input_proj + FiLM, the first upsamplers), then fp32 storage: the "
+                              "last upsamplers and the output conv with every MFMA operand split into hi + lo bf16 (3 products per MAC), the three MRF "
+                              "blocks with hi + lo f16 activation operands x %s; fp32 accumulate throughout"
+                              % (MIXED_THROUGH, "single f16 weights (2 products per MAC)" if MIXED_MRF_W16 else "hi + lo bf16 weights (3 products)"),
                      "fp32": "fp32 storage; every MFMA operand split into hi + lo bf16 (3 products per MAC), fp32 accumulate",
                      "bf16": "bf16 storage and MFMA operands, fp32 accumulate", "fp16": "fp16 storage and MFMA operands, fp32 accumulate"}[args.dtype]
         out = {
-            "metric": "mel-frames/s vocoded (V1 80-mel 22.05kHz generator, ODConv + GRC-LoRA)",
+            "metric": "mel-frames/s vocoded (V1 80-mel 22.05kHz generator, ODConv + GRC-LoRA" + ("; mixed fp16 + fp32 storage: the fastest "
+                      "mode inside north_star's 1e-3 - BASELINE's bf16 storage is reported under bf16_storage with parity_ok false)" if args.dtype == "mixed" else ")"),
             "value": round(frames / elapsed, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "fp16+fp32" if args.dtype == "mixed" else args.dtype, "precision": precision, "data": "synthetic",
@@ -648,6 +667,8 @@ def main():
                 modes[tag]["parity_rel_l2_vs_oracle"] = par.get("mode_" + tag)
                 modes[tag]["parity_ok"] = ok(par.get("mode_" + tag))
             out["cpu_baseline"] = cb
+        if modes and "bf16" in modes:      # the storage type BASELINE configs[1] names, first-class beside the headline
+            out["bf16_storage"] = {k: modes["bf16"][k] for k in ("value", "unit", "ms_per_step", "parity_rel_l2_vs_oracle", "parity_ok")}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -181,7 +181,9 @@ int mv_mrf_block_fwd_cl(const void* x, void* out, const void* packed, const int*
  * / grc_lora.py:157-163, eval mode).  Same arithmetic as nblocks calls of mv_mrf_block_fwd_cl, restructured: block i writes its
  * pre-GroupNorm fusion output once, and GroupNorm(8,64) + the residual add of block i are applied by block i+1's first pass while it
  * loads its input (2 launches and 320 MFMAs per 64-step tile and block instead of 3 and 512).  packed[i] = mv_mrf_pack of block i,
- * dilations = nblocks x 3 ints, workspace >= mv_mrf_chain_workspace_bytes bytes (256-byte aligned, fully rewritten per call). */
+ * dilations = nblocks x 3 ints, workspace >= mv_mrf_chain_workspace_bytes bytes (256-byte aligned, fully rewritten per call).
+ * dtype MV_F32_W16 (fp32 x / out, packed[i] = the MV_F16 image): two-product operands; with the reference's dilations (1, 3, 5) the
+ * passes run in their streaming form (csrc/mrf_stream.hip).  out may be NULL: the passes run and nothing is materialised (timing). */
 size_t mv_mrf_chain_workspace_bytes(int B, int T, int dtype);
 int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* packed, const int* dilations, int nblocks, void* workspace,
                         int B, int T, float eps, int dtype, void* stream);
