@@ -1330,6 +1330,354 @@ extern "C" int mv_odconv_cl_pack(const void* kernels, int param_dtype, void* pac
   return MV_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ streaming variant
+// The last two upsamplers in fp32 storage (ODConvTranspose1d, ks = 2 * stride, 256-byte input rows: 64 fp32 channels or 128 fp16
+// channels, small banks, long sequences).  The multi-tile kernel above moves 1.5-2.9 TB/s here: four waves share an x tile between
+// two barriers per 64 columns, each wave redoes commit -> barrier -> MFMAs -> stores in step with the others.  This form follows the
+// streaming MRF passes (mrf_stream.hip):
+//   * one workgroup of 8 waves per CU; the sample's aggregated kernel sum_k alpha_k W_k is formed ONCE per workgroup (each wave mixes
+//     its share of the bank fragments) and kept in LDS as f16 hi + lo fragment images, scaled by 2^6 so the lo parts stay clear of
+//     the f16 subnormal floor (the matrix pipe keeps f16 subnormals - measured - the scale is a margin, and it is exact);
+//   * every wave owns a span of L input columns and walks it in 16-column tiles from a PRIVATE two-slot ring (+ a one-row carry for
+//     the second tap): no workgroup barrier after the prologue; the rows of tiles j + 1 and j + 2 are in flight in registers;
+//   * fp16 rows are exact f16 operands (a_hi x + a_lo x: two products); fp32 rows are split into f16 hi + lo as they are committed
+//     (three products); out-of-range rows arrive as zeros and out-of-range output rows are dropped by the buffer range check.
+// A wave writes all M rows of its columns (M / Cout whole output rows per input column).
+constexpr int OS_NW = 8, OS_RB = 256, OS_RS = OS_RB + 16, OS_SLOT = 16 * OS_RS, OS_RING = 2 * OS_SLOT + OS_RS;
+constexpr float OS_WSCALE = 64.f, OS_WUNSCALE = 1.f / 64.f;
+#ifdef MV_OS_TIMING
+__device__ long long* os_dbg = nullptr;   // [wave][8]: alpha, bias + aggregation, first fill, tiles (compute), tiles (carry + commit), pooled, total
+#define OS_TM(slot) do { const long long t_ = clock64(); tacc[slot] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define OS_TM(slot) do {} while (0)
+#endif
+
+template <int CIN, int MT, bool XF16>
+__global__ __launch_bounds__(OS_NW * 64) void odconv_stream_kernel(const void* __restrict__ x, const float* __restrict__ wp,
+                                                                  const float* __restrict__ bias, const float* __restrict__ alpha_in,
+                                                                  const float* __restrict__ pooled_in, const float* __restrict__ att_w,
+                                                                  const float* __restrict__ att_b, float* __restrict__ y,
+                                                                  float* __restrict__ pooled_out, OdP p, int L) {
+  static_assert((XF16 ? CIN * 2 : CIN * 4) == OS_RB, "256-byte input rows");
+  constexpr int CPC = CIN / 8, KST = 2 * CIN / 32, NF = MT * KST, KB = 4;
+  constexpr int GB = XF16 ? 16 : 32;                     // bytes of one 8-channel group in an LDS row (f16 | f16 hi + lo)
+  using MH = Mma<f16>;
+  extern __shared__ __align__(16) char lds[];
+  char* aimg = lds;                                      // [NF][hi 1 KB | lo 1 KB]
+  float* alds = reinterpret_cast<float*>(lds + NF * 2048);
+  float* bias_l = alds + OD_MAXK;                        // [MT * 16]
+  float* red = bias_l + MT * 16;                         // [OS_NW][MT * 16]
+  char* rings = reinterpret_cast<char*>(red + OS_NW * MT * 16);
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.z, R0 = blockIdx.y * MT * 16, n_mt = p.M / 16;
+  const int ring = (int)(rings - lds) + wid * OS_RING, carry = ring + 2 * OS_SLOT;
+#ifdef MV_OS_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+  const long long tfirst = tlast, t_abs0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // ---- this wave's span of input columns (the sample's last wave also takes the ragged end: nq = Tin + 1 leaves one column over)
+  const int wave_id = blockIdx.x * OS_NW + wid;
+  const int s0 = wave_id * L;
+  const int span = (wave_id == gridDim.x * OS_NW - 1 ? p.nq : min(p.nq, s0 + L)) - s0;
+  const int nt = span > 0 ? (span + 15) >> 4 : 0;
+  const long xsample = (long)b * p.Tin * OS_RB;
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)) + xsample, 0, p.Tin * OS_RB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(y) + (long)b * p.Tout * p.Cout * 4, 0, p.Tout * p.Cout * 4, 0x00020000);
+  // staging: a batch = 16 rows x 256 B = 4 x 16 B per lane.  fp16 rows: lane -> 16-byte chunk (lane & 15) of rows (lane >> 4) + 4 k;
+  // fp32 rows: lane -> 8-channel group (lane & 7) of rows (lane >> 3) + 8 k, two 16-byte pieces each
+  auto row_of = [&](int k) { return XF16 ? (lane >> 4) + 4 * k : (lane >> 3) + 8 * (k >> 1); };
+  auto off_of = [&](int k) { return XF16 ? (lane & 15) * 16 : (lane & 7) * 32 + (k & 1) * 16; };
+  u32x4 ra[4], rb[4];
+  auto issue = [&](u32x4 (&r)[4], int jb) {              // batch jb = input rows s0 + 16 jb ..
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      r[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (s0 + 16 * jb + row_of(k)) * OS_RB + off_of(k), 0, 0);
+  };
+  auto put = [&](int dst_row0, int r, int k, const u32x4& v0, const u32x4& v1) {
+    // XF16: one 16-byte chunk as it is; fp32: an 8-channel group (v0, v1) -> f16 hi | lo
+    if constexpr (XF16) {
+      *reinterpret_cast<u32x4*>(lds + dst_row0 + r * OS_RS + off_of(k)) = v0;
+    } else {
+      const f32x4 a = __builtin_bit_cast(f32x4, v0), c = __builtin_bit_cast(f32x4, v1);
+      uint32_t h[4], l[4];
+      Mma<f32w16>::split2(a[0], a[1], h[0], l[0]); Mma<f32w16>::split2(a[2], a[3], h[1], l[1]);
+      Mma<f32w16>::split2(c[0], c[1], h[2], l[2]); Mma<f32w16>::split2(c[2], c[3], h[3], l[3]);
+      char* d = lds + dst_row0 + r * OS_RS + (lane & 7) * 32;
+      *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+      *reinterpret_cast<u32x4*>(d + 16) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
+  auto commit = [&](const u32x4 (&r)[4], int slot) {
+    if constexpr (XF16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) put(ring + slot * OS_SLOT, row_of(k), k, r[k], r[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) put(ring + slot * OS_SLOT, row_of(k), k, r[k], r[k + 1]);
+    }
+  };
+  // ---- prologue: attention chain (three dependent round trips on a cold chip: ~11.6 k cycles), then this wave's share of the bank
+  //      fragments (256 KB per workgroup through the CU's memory path: ~10 k cycles) with the first rows of the span right behind them
+  u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+  const bool carry_mine = XF16 ? lane < 16 : lane < 8;
+  auto first_rows = [&]() {
+    if (nt > 0) {
+      if (carry_mine) {
+        c0 = __builtin_amdgcn_raw_buffer_load_b128(rx, (s0 - 1) * OS_RB + (XF16 ? lane * 16 : lane * 32), 0, 0);
+        if constexpr (!XF16) c1 = __builtin_amdgcn_raw_buffer_load_b128(rx, (s0 - 1) * OS_RB + lane * 32 + 16, 0, 0);
+      }
+      issue(ra, 0);
+      if (nt > 1) issue(rb, 1);
+    }
+  };
+  constexpr int FPW = NF / OS_NW;                        // fragments per wave
+  static_assert(NF % OS_NW == 0, "fragments split evenly over the waves");
+  WLoad<float>::R wr[FPW][KB];
+  auto frag_loads = [&]() {
+    const long bank_stride = (long)n_mt * KST * 512;      // floats
+    const float* wlane = wp + (long)lane * 8;
+#pragma unroll
+    for (int u = 0; u < FPW; ++u) {
+      const int f = wid * FPW + u;
+      const int mtl = f / KST, ks = f - mtl * KST;
+      const int mt = (blockIdx.y * MT + mtl) < n_mt ? (blockIdx.y * MT + mtl) : (n_mt - 1);
+      const float* wbase = wlane + ((long)mt * KST + ks) * 512;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) wr[u][kb] = WLoad<float>::load(reinterpret_cast<const char*>(wbase + (kb < p.K ? kb : 0) * bank_stride));
+    }
+  };
+  // vector-memory results return in issue order per wave: the waves that load the attention chain's partial sums and weights (0-3)
+  // must not queue 32 fragment loads in front of them; the other half of the workgroup has nothing else to wait for
+  // (measured: requesting any of this under the attention chain only queues the chain's own small loads behind it in the CU's memory
+  //  path - 172 KB requested by the idle half of the workgroup took the chain from 11.6 k to 33 k cycles; the order that works is chain
+  //  first, then the fragments, with the rows of the first tiles right behind them)
+  constexpr bool early = false;
+
+  if (alpha_in) {
+    if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+  } else {
+    od_alpha_from_partials<float>(alds, reinterpret_cast<float*>(rings), 1, b, p, pooled_in, att_w, att_b);   // rings: nothing staged yet
+  }
+  __syncthreads();
+  OS_TM(0);
+  if (!early) { frag_loads(); first_rows(); }
+  float al[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) al[kb] = kb < p.K ? alds[kb] : 0.f;
+  if (tid < MT * 16) {
+    const int row = R0 + tid;
+    float a = 0.f;
+    if (bias && row < p.M)
+      for (int kb = 0; kb < p.K; ++kb) a += al[kb] * bias[(long)kb * p.Cout + row % p.Cout];
+    bias_l[tid] = a;
+  }
+  // this sample's kernel, once per workgroup: fragment f = (local M-tile, k-step) -> hi / lo f16 images
+#pragma unroll
+  for (int u = 0; u < FPW; ++u) {
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) WLoad<float>::fma8(wr[u][kb], al[kb] * OS_WSCALE, f);
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Mma<f32w16>::split2(f[2 * e], f[2 * e + 1], h[e], l[e]);
+    char* dst = aimg + (size_t)(wid * FPW + u) * 2048 + lane * 16;
+    *reinterpret_cast<u32x4*>(dst) = u32x4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(dst + 1024) = u32x4{l[0], l[1], l[2], l[3]};
+  }
+  if (nt > 0) {                                          // (the alpha scratch in `rings` is dead: od_alpha_from_partials ends behind a barrier)
+    if (carry_mine) put(carry, 0, 0, c0, c1);
+    commit(ra, 0);
+  }
+  __syncthreads();
+  OS_TM(1);
+
+  // B-operand bases of this lane: k-step ks -> chunk 4 ks + g -> (tap, 8-channel group); tap 0 reads row col of the tile's slot, tap 1
+  // row col - 1 (column 0: the carry row = the last row of the previous batch)
+  int baddr[KST][2];
+#pragma unroll
+  for (int ks = 0; ks < KST; ++ks) {
+    const int chunk = 4 * ks + g, tap = chunk / CPC, c8 = chunk % CPC;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      baddr[ks][u] = (tap == 1 && col == 0) ? carry + c8 * GB : ring + u * OS_SLOT + (col - tap) * OS_RS + c8 * GB;
+  }
+  // output rows of this lane: GEMM row R0 + 16 m + 4 g (+ i) = (phase, channel); u = q * stride + phase - pad
+  int vo[MT], uofs[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int row = R0 + 16 * m + 4 * g, rr = row / p.Cout, o = row - rr * p.Cout;
+    uofs[m] = rr - p.pad;
+    vo[m] = (uofs[m] * p.Cout + o) * 4;
+  }
+  const float slope = p.act == ACT_NONE ? 1.f : p.slope;
+  float psum[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) psum[m][i] = 0.f;
+
+  auto tile = [&](auto uc, int j) {
+    constexpr int U = decltype(uc)::value;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // flat (k-step, M-tile) sequence, operands one step ahead of their MFMAs
+    MH::V bh[2], bl[2], ah[2], alo[2];
+    auto ldb = [&](int ks, int set) {
+      bh[set] = MH::load_b(lds + baddr[ks][U]);
+      if constexpr (!XF16) bl[set] = MH::load_b(lds + baddr[ks][U] + 16);
+    };
+    auto lda = [&](int sq, int set) {
+      const int ks = sq / MT, m = sq % MT;
+      const char* ap = aimg + (size_t)(m * KST + ks) * 2048 + lane * 16;
+      ah[set] = MH::load_b(ap);
+      alo[set] = MH::load_b(ap + 1024);
+    };
+    ldb(0, 0);
+    lda(0, 0);
+#pragma unroll
+    for (int sq = 0; sq < NF; ++sq) {
+      const int ks = sq / MT, m = sq % MT;
+      if (sq + 1 < NF) {
+        lda(sq + 1, (sq + 1) & 1);
+        if ((sq + 1) % MT == 0) ldb(ks + 1, (ks + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      acc[m] = MH::mma(alo[sq & 1], bh[ks & 1], acc[m]);
+      if constexpr (!XF16) acc[m] = MH::mma(ah[sq & 1], bl[ks & 1], acc[m]);
+      acc[m] = MH::mma(ah[sq & 1], bh[ks & 1], acc[m]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue: un-scale, mixed bias, activation, pooling sums for the next layer's attention, 16-byte stores (rows outside the sample
+    // are dropped by the range check)
+    const int q = s0 + 16 * j + col;
+    const int qo = q * p.stride * p.Cout * 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + 16 * m + 4 * g);
+      const int uu = q * p.stride + uofs[m];
+      const bool ok = q < p.nq && uu >= 0 && uu < p.Tout && (R0 + 16 * m) < p.M;
+      f32x4 ov;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = acc[m][i] * OS_WUNSCALE + bv[i];
+        ov[i] = v >= 0.f ? v : v * slope;
+        psum[m][i] += ok ? ov[i] : 0.f;
+      }
+      if ((R0 + 16 * m) < p.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), ry, qo + vo[m], 0, 0);
+    }
+  };
+
+  if (nt > 0) {
+    auto step = [&](auto uc, int j, u32x4 (&rnext)[4], u32x4 (&rfree)[4]) {
+      // on entry: batch j is in slot U, batch j + 1 travels in rnext; rfree takes batch j + 2
+      constexpr int U = decltype(uc)::value;
+      if (j + 2 < nt) issue(rfree, j + 2);
+      tile(uc, j);
+      OS_TM(3);
+      if (j + 1 < nt) {
+        // the next tile's carry = the last row of this batch; then batch j + 1 lands in the other slot
+        if (lane < 16) {
+          const u32x4 t_ = *reinterpret_cast<const u32x4*>(lds + ring + U * OS_SLOT + 15 * OS_RS + lane * 16);
+          *reinterpret_cast<u32x4*>(lds + carry + lane * 16) = t_;
+        }
+        commit(rnext, U ^ 1);
+      }
+      OS_TM(4);
+    };
+    for (int j = 0; j < nt; j += 2) {
+      step(std::integral_constant<int, 0>{}, j, rb, ra);
+      if (j + 1 < nt) step(std::integral_constant<int, 1>{}, j + 1, ra, rb);
+    }
+  }
+#ifdef MV_OS_TIMING
+  if (lane == 0 && os_dbg) {
+    const long w = (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * OS_NW + wid;
+    if (w < 65536) {
+      long long* d = os_dbg + w * 8;
+      for (int i = 0; i < 5; ++i) d[i] = tacc[i];
+      d[5] = clock64() - tfirst; d[6] = t_abs0; d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
+
+  if (pooled_out) {                                      // one partial per (row, workgroup): slot blockIdx.x of this sample
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = psum[m][i];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (col == 0) red[wid * MT * 16 + 16 * m + 4 * g + i] = v;
+      }
+    __syncthreads();
+    if (tid < MT * 16 && R0 + tid < p.M) {
+      float a = 0.f;
+      for (int w = 0; w < OS_NW; ++w) a += red[w * MT * 16 + tid];
+      pooled_out[((long)b * gridDim.x + blockIdx.x) * p.M + R0 + tid] = a;
+    }
+  }
+}
+
+template <int CIN, int MT, bool XF16>
+static int od_stream_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
+                            const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream, int* slots_out) {
+  constexpr int KST = 2 * CIN / 32;
+  if ((long)p.Tin * OS_RB >= (1l << 31) || (long)p.Tout * p.Cout * 4 >= (1l << 31) || p.Cout % 16 || p.K > 4) return MV_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)MT * KST * 2048 + sizeof(float) * (OD_MAXK + MT * 16 + OS_NW * MT * 16) + (size_t)OS_NW * OS_RING;
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  const int gy = cdiv(p.M / 16, MT);
+  // nq = Tin + 1 columns: the odd one is taken by the sample's last wave (a 257th tile would cost every wave a fifth tile at C2)
+  const int tiles = p.nq >= 32 ? (p.nq - 1) / 16 : cdiv(p.nq, 16);
+  const int wgs = 256 / (p.B * gy) > 1 ? 256 / (p.B * gy) : 1;     // workgroups per (sample, row block) that fill the chip once
+  int tpw = cdiv(tiles, wgs * OS_NW);
+  if (tpw < 1) tpw = 1;
+  const int gx = cdiv(tiles, tpw * OS_NW);
+  if (slots_out) { *slots_out = gx; return MV_OK; }
+  if (gy > 65535 || p.B > 65535) return MV_ERR_UNSUPPORTED;
+  auto kern = odconv_stream_kernel<CIN, MT, XF16>;
+  static bool set = false;
+  if (!set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+#ifdef MV_OS_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { (void)hipMalloc(&dbg, 65536 * 8 * 8); (void)hipMemcpyToSymbol(HIP_SYMBOL(os_dbg), &dbg, sizeof(dbg)); }
+  (void)hipMemsetAsync(dbg, 0xff, 65536 * 8 * 8, stream);
+#endif
+  hipLaunchKernelGGL(kern, dim3(gx, gy, p.B), dim3(OS_NW * 64), lds, stream, x, (const float*)wp, (const float*)bias, alpha, pooled_in,
+                     (const float*)att_w, (const float*)att_b, (float*)y, pooled_out, p, tpw * 16);
+#ifdef MV_OS_TIMING
+  {
+    const char* e = getenv("MV_MRF_TIMING_CALL");
+    if (++calls == (e ? atoi(e) : 30)) {
+      (void)hipStreamSynchronize(stream);
+      static long long hbuf[65536 * 8];
+      (void)hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+      double av[6] = {0}; int cnt = 0; long long tmin = -1, tmax = -1;
+      for (int w = 0; w < 65536; ++w) {
+        const long long* d = hbuf + (size_t)w * 8;
+        if (d[5] < 0) continue;
+        for (int k = 0; k < 6; ++k) av[k] += (double)d[k];
+        ++cnt;
+        if (tmin < 0 || d[6] < tmin) tmin = d[6];
+        if (d[7] > tmax) tmax = d[7];
+      }
+      if (cnt) fprintf(stderr, "[od stream timing] Cin %d MT %d grid %d x %d x %d tpw %d waves %d: span %.2f us; per wave cycles: alpha %.0f bias+mix %.0f first fill %.0f tiles %.0f carry+commit %.0f total %.0f\n",
+                       CIN, MT, gx, gy, p.B, tpw, cnt, (tmax - tmin) / 100.0, av[0] / cnt, av[1] / cnt, av[2] / cnt, av[3] / cnt, av[4] / cnt, av[5] / cnt);
+    }
+  }
+#endif
+  return MV_OK;
+}
+
 // Picks the kernel variant for a layer and launches it - or, with slots_out, only reports how many partial-sum slots per sample
 // that launch writes to pooled_out (the variant sets the grid, so the caller sizes pooled_out from the same decision).
 static int od_dispatch(const void* x, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
@@ -1401,7 +1749,14 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
             if (Cin == 64) rc = od_mt_launch<T, 2, 8, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
             else rc = od_mt_launch<T, 2, 4, 128>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
           } else {   // fp32 (operands are hi/lo register pairs): 64-column tiles; at 128 channels ONE M-tile per wave (two cost a wave per SIMD: 60 us)
-            if (p.in_f16) {
+            static int os_on = -1;
+            if (os_on < 0) { const char* e = getenv("MV_OD_STREAM"); os_on = e ? atoi(e) : 1; }
+            if (os_on && act <= ACT_LRELU) {    // streaming form: 256-byte input rows (64 fp32 / 128 fp16 channels)
+              if (p.in_f16 && Cin == 128) rc = od_stream_launch<128, 4, true>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+              else if (!p.in_f16 && Cin == 64) rc = od_stream_launch<64, 8, false>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+            }
+            if (rc != MV_ERR_UNSUPPORTED) { /* launched (or sized) */ }
+            else if (p.in_f16) {
               if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
               else rc = od_mt_launch<T, 1, 4, 128, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
             } else if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
@@ -1457,8 +1812,14 @@ extern "C" int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, cons
 
 extern "C" size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
                                          int transposed, int K, int act, int has_film, int dtype) {
+  return mv_odconv_cl_pool_floats_in(B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, has_film, dtype, 0);
+}
+
+extern "C" size_t mv_odconv_cl_pool_floats_in(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                                            int transposed, int K, int act, int has_film, int dtype, int in_f16) {
   OdP p;
   if (!od_make(&p, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, 0.1f, has_film ? 8 : 0)) return 0;
+  p.in_f16 = (in_f16 && dtype == MV_F32) ? 1 : 0;
   int slots = 0;
   static const int dummy = 0;   // non-null stand-ins: the dry run launches nothing and touches no memory
   const void* d = &dummy;

@@ -280,11 +280,15 @@ class OdconvFused:
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         return (Tin - 1) * stride - 2 * pad + ks + m.output_padding if tr else Tin + 2 * pad - dil * (ks - 1)
 
-    def pool_floats(self, B, Tin, dtype, act=N.ACT_NONE, has_film=False):
-        """floats per sample of the partial-sum buffer (`pooled_out`) this layer's launch writes for its consumer's attention."""
+    def pool_floats(self, B, Tin, dtype, act=N.ACT_NONE, has_film=False, in_f16=False):
+        """floats per sample of the partial-sum buffer (`pooled_out`) this layer's launch writes for its consumer's attention.
+        in_f16: the launch is the mixed mode's first fp32 stage reading the fp16 stream (mv_odconv_cl_fwd_in16)."""
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
-        n = N.lib().mv_odconv_cl_pool_floats(B, cin, Tin, cout, self.out_len(Tin), ks, stride, pad, dil, int(tr), K, int(act),
-                                             int(has_film), ops._DT[dtype])
+        n = N.lib().mv_odconv_cl_pool_floats_in(B, cin, Tin, cout, self.out_len(Tin), ks, stride, pad, dil, int(tr), K, int(act),
+                                                int(has_film), ops._DT[dtype], int(in_f16))
+        if n == 0 and in_f16:                # no input-widening variant for this geometry: forward_cl casts and takes the plain entry
+            n = N.lib().mv_odconv_cl_pool_floats_in(B, cin, Tin, cout, self.out_len(Tin), ks, stride, pad, dil, int(tr), K, int(act),
+                                                    int(has_film), ops._DT[dtype], 0)
         if n == 0:
             raise RuntimeError("odconv_cl: unsupported geometry")
         return n
@@ -376,7 +380,8 @@ class GeneratorFused:
         prods = [self.inp] + self.ups[:-1]
         lens, T_ = [], mel.shape[2]
         for j, pr in enumerate(prods):
-            lens.append(pr.pool_floats(B, T_, sdt(j), N.ACT_NONE if j == 0 else N.ACT_LRELU, has_film=(j == 0 and has_cond)))
+            lens.append(pr.pool_floats(B, T_, sdt(j), N.ACT_NONE if j == 0 else N.ACT_LRELU, has_film=(j == 0 and has_cond),
+                                       in_f16=(j >= 1 and sdt(j) == torch.float32 and sdt(j - 1) == torch.float16)))
             T_ = pr.out_len(T_)
         nflat = sum(B * n for n in lens)
         P = lambda t: None if t is None else c_void_p(t.data_ptr())

@@ -229,6 +229,9 @@ int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, const void* bia
  * count follows the kernel variant the dispatcher picks for this geometry. */
 size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
                                 int transposed, int K, int act, int has_film, int dtype);
+/* the same for a launch through mv_odconv_cl_fwd_in16 (in_f16 != 0, dtype MV_F32): the input-widening variants set their own grids */
+size_t mv_odconv_cl_pool_floats_in(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,
+                                   int transposed, int K, int act, int has_film, int dtype, int in_f16);
 /* Generator prologue in one launch: input_proj's attention alpha fp32 [B][K] (odconv.py:36-40) and mel [B][C][T] -> x_cl [B][T][C]
  * (one workgroup per sample), the FiLM projection film_proj [B][F2] = W cond + b with cond = cat(spk [B][ds], emo [B][de])
  * truncated / zero-padded to cond_dim (grc_lora.py:82-105; film_proj NULL = no conditioning; extra workgroups of the same grid,

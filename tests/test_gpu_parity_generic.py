@@ -548,7 +548,9 @@ def test_output_conv_packed_images_vs_fp64(H, dtype, B, T, ks):
 
 def test_mixed_mode_entry_points_match_their_cast_forms(H):
     """The two entry points that let the mixed storage mode change type without cast launches, against cast + the plain entry point:
-    mv_odconv_cl_fwd_in16 (fp32 ODConvTranspose1d fed an fp16 stream: widening is exact, so the result is bit-identical) and
+    mv_odconv_cl_fwd_in16 (fp32 ODConvTranspose1d fed an fp16 stream: widening is exact; the two entries may pick different kernels -
+    the streaming form with f16 hi + lo operands vs the multi-tile form with bf16 hi + lo - so they agree to fp32-grade rounding, and
+    the widening entry agrees with an fp64 transposed convolution of the same fp16 values) and
     mv_gen_prologue_in (fp16 prologue fed fp32 mel / embeddings: x_cl and the FiLM projection see the same rounded inputs; the
     attention weights are formed from the unrounded mel, i.e. agree to fp16 rounding of the mean)."""
     from ctypes import c_void_p
@@ -565,7 +567,13 @@ def test_mixed_mode_entry_points_match_their_cast_forms(H):
     alpha = torch.softmax(torch.randn(B, u.mod.K, device="cuda"), 1)
     y_cast = u.forward_cl(x16.float(), Fn._cache, alpha=alpha, act=N.ACT_LRELU)
     y_in16 = u.forward_cl(x16, Fn._cache, alpha=alpha, act=N.ACT_LRELU, storage=torch.float32)
-    assert y_in16.dtype == torch.float32 and torch.equal(y_cast, y_in16)
+    assert y_in16.dtype == torch.float32 and O.rel_l2(y_in16.cpu(), y_cast.cpu()) < 2e-5
+    wagg = torch.einsum("bk,kcoj->bcoj", alpha.double(), u.mod.kernels.double())
+    bagg = alpha.double() @ u.mod.bias.double()
+    ref = torch.stack([torch.nn.functional.conv_transpose1d(x16[i].double().t()[None], wagg[i], bagg[i], stride=u.mod.stride,
+                                                            padding=u.mod.padding)[0] for i in range(B)])
+    ref = torch.nn.functional.leaky_relu(ref, 0.1).transpose(1, 2)
+    assert O.rel_l2(y_in16.double().cpu(), ref.cpu()) < 2e-6, O.rel_l2(y_in16.double().cpu(), ref.cpu())
     # a geometry without the widening variant falls back to the cast inside forward_cl (first upsampler: K-loop kernel)
     u0 = fz.ups[0]
     x0 = torch.randn(B, 32, u0.mod.in_channels, device="cuda").half()
