@@ -544,7 +544,7 @@ extern "C" int mv_conv1d_wgrad(const void* x, const void* gy, const void* w, con
   float* dst = per_sample ? workspace : gw;
   // ODConv (nbanks > 1): per-sample tiles first (no cross-sample contention), then one reduction applies the alpha chain
   if (!per_sample || tsplit > 1)
-    MV_HIP(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)(per_sample ? B : 1) * nelem, (hipStream_t)stream));
+    MV_HIP(mvi_zero_async(dst, sizeof(float) * (size_t)(per_sample ? B : 1) * nelem, (hipStream_t)stream));
   MV_DISPATCH(dtype, {
     hipLaunchKernelGGL(conv1d_wgrad_kernel<T>, grid, dim3(256), lds, (hipStream_t)stream, (const T*)x, (const T*)gy,
                        (const T*)w, alpha, dst, galpha, B, Cin, Tin, Cout, Tout, ks, stride, pad, dil, nbanks, x_bs, x_cs,
@@ -645,7 +645,7 @@ extern "C" int mv_groupnorm_bwd(const void* x, const void* gy, const float* mean
 extern "C" int mv_film_bwd(const void* x, const void* gy, const void* proj, void* gx, float* gproj, int B, int C, int T_,
                            int F, int dtype, void* stream) {
   MV_CHECK_ARG(x && gy && proj && gx && gproj && B > 0 && C > 0 && T_ > 0 && F > 0);
-  MV_HIP(hipMemsetAsync(gproj, 0, sizeof(float) * (size_t)B * 2 * F, (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(gproj, sizeof(float) * (size_t)B * 2 * F, (hipStream_t)stream));
   MV_DISPATCH(dtype, hipLaunchKernelGGL(film_bwd_kernel<T>, dim3(B * C), dim3(256), 0, (hipStream_t)stream, (const T*)x,
                                         (const T*)gy, (const T*)proj, (T*)gx, gproj, C, T_, F));
   MV_LAUNCH_CHECK();

@@ -124,6 +124,12 @@ int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, in
                          float eps, hipStream_t stream, const void** f_last, const void** x_last, int* x_last_pair,
                          const float** part8_last, const float** tab_last, int* nwg_last);
 
+// Zero fill as a KERNEL launch.  hipMemsetAsync becomes a memset node when a stream is being captured, and on this ROCm build a memset
+// node is not reliably ordered in front of the kernel node that follows it in a replayed graph: a captured training step whose
+// weight-gradient kernels accumulate with atomics onto a freshly zeroed buffer produced inf gradients from its second replay on as
+// soon as the replays were not issued back to back (tests/test_gpu_train_graph.py).  A kernel node has no such problem.
+hipError_t mvi_zero_async(void* p, size_t bytes, hipStream_t stream);
+
 #define MV_CHECK_ARG(cond) do { if (!(cond)) return MV_ERR_ARG; } while (0)
 // runtime calls that are not kernel launches: propagate the hipError_t as the entry point's (positive) return code
 #define MV_HIP(call) do { const hipError_t mv_e_ = (call); if (mv_e_ != hipSuccess) return (int)mv_e_; } while (0)

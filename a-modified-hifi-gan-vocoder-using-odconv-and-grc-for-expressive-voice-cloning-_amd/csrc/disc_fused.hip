@@ -1575,8 +1575,8 @@ extern "C" int mv_dhead_dgrad(const void* g, const void* packed, const void* xsa
 extern "C" int mv_dhead_wgrad(const void* g, const void* x, float* gw, float* gb, int B, int H, int W, int C, int kh, int kw,
                               int dtype, void* stream) {
   MV_CHECK_ARG(g && x && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C <= 1024 && C % 64 == 0);
-  MV_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)kh * kw * C, (hipStream_t)stream));
-  MV_HIP(hipMemsetAsync(gb, 0, sizeof(float), (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(gw, sizeof(float) * (size_t)kh * kw * C, (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(gb, sizeof(float), (hipStream_t)stream));
   MV_CHECK_ARG(kw <= DH_MAXTAPS && H <= 65535);
   if (dtype != MV_F32 && ((uintptr_t)x & 15) == 0) {   // 16-byte channel vectors: register-tiled reduction
     int rc = MV_ERR_UNSUPPORTED;
@@ -1696,10 +1696,10 @@ extern "C" int mv_dconv_wgrad_cl(const void* x, const void* g, float* gw, float*
   hipStream_t s = (hipStream_t)stream;
   const size_t wn = (size_t)Cout * Cin * kh * kw;
   if (gb && gb == workspace + wn) {                  // bias sums placed right behind the workspace: one fill instead of two
-    MV_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * (wn + Cout), s));
+    MV_HIP(mvi_zero_async(workspace, sizeof(float) * (wn + Cout), s));
   } else {
-    MV_HIP(hipMemsetAsync(workspace, 0, sizeof(float) * wn, s));
-    if (gb) MV_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)Cout, s));
+    MV_HIP(mvi_zero_async(workspace, sizeof(float) * wn, s));
+    if (gb) MV_HIP(mvi_zero_async(gb, sizeof(float) * (size_t)Cout, s));
   }
   int rc = MV_ERR_UNSUPPORTED;
   if (dtype == MV_BF16) rc = dwgrad_dispatch<bf16>(x, g, workspace, gb, B, H, W, Cin, Cout, kh, kw, dil_w, s);
@@ -1827,7 +1827,7 @@ extern "C" int mv_odconvT_wgrad_mfma(const void* x_cl, const void* gp, const voi
   float* tiles = (float*)workspace;                                           // [B][2][Cin][s*Cout]
   char* wtm = (char*)(tiles + n * B);                                         // [K][2][Cin][s*Cout] in `dtype`
   float* gtm = (float*)(wtm + ((size_t)2 * n * K + 255) / 256 * 256);         // [K][2][Cin][s*Cout] fp32
-  MV_HIP(hipMemsetAsync(tiles, 0, sizeof(float) * (size_t)n * B, s));
+  MV_HIP(mvi_zero_async(tiles, sizeof(float) * (size_t)n * B, s));
   // "g" operand = x (rows = input channels), "x" operand = padded gradient rows (columns = (r, o)), taps q = 0, 1
   int rc;
   if (dtype == MV_BF16) rc = dwgrad_launch<bf16, 1, 2, 128>(gp, x_cl, tiles, nullptr, B, 1, Tin, stride * Cout, Cin, 1, s, Tin + 1, n);
@@ -1905,8 +1905,8 @@ extern "C" int mv_dfirst_dgrad_cl(const void* g1, const void* w, void* gx0, floa
 extern "C" int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, float* gb, int B, int H, int W, int C1, int kh,
                                   int kw, int dtype, void* stream) {
   MV_CHECK_ARG(g1 && x0 && gw && gb && B > 0 && B <= 65535 && H > 0 && W > 0 && C1 > 0 && 256 % C1 == 0);
-  MV_HIP(hipMemsetAsync(gw, 0, sizeof(float) * (size_t)C1 * kh * kw, (hipStream_t)stream));
-  MV_HIP(hipMemsetAsync(gb, 0, sizeof(float) * (size_t)C1, (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(gw, sizeof(float) * (size_t)C1 * kh * kw, (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(gb, sizeof(float) * (size_t)C1, (hipStream_t)stream));
   if (dtype != MV_F32 && ((uintptr_t)g1 & 15) == 0) {
     int rc = MV_ERR_UNSUPPORTED;
     if (dtype == MV_BF16) rc = dtap_launch<bf16>(g1, x0, gw, gb, B, H, W, C1, kh, kw, 0, kh * kw, 1, 1, (hipStream_t)stream);
@@ -1923,7 +1923,7 @@ extern "C" int mv_dfirst_wgrad_cl(const void* g1, const void* x0, float* gw, flo
 
 extern "C" int mv_colsum_cl(const void* x, float* out, long rows, int C, int dtype, void* stream) {
   MV_CHECK_ARG(x && out && rows > 0 && C >= 8 && C <= 2048 && C % 8 == 0 && (256 % (C / 8)) == 0 && ((uintptr_t)x & 15) == 0);
-  MV_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, (hipStream_t)stream));
+  MV_HIP(mvi_zero_async(out, sizeof(float) * (size_t)C, (hipStream_t)stream));
   if (dtype == MV_F32 && (256 % (C / 4)) != 0) return MV_ERR_UNSUPPORTED;
   const int chunk = 2048;
   MV_DISPATCH(dtype, hipLaunchKernelGGL(colsum_cl_kernel<T>, dim3((unsigned)((rows + chunk - 1) / chunk)), dim3(256), 0,

@@ -1,6 +1,7 @@
 // ODConv attention, GroupNorm (two-phase), FiLM, activations, pooling, MPD fold, layout transposes,
 // casts, small dense layers and the GRC+LoRA weight fold.  Generic shapes, NCT layout.
 #include "common.h"
+#include "mfma.h"
 
 namespace mv {
 
@@ -842,4 +843,33 @@ extern "C" int mv_grc_fold_weights(const void* conv_w, const void* conv_b, const
   }
   MV_LAUNCH_CHECK();
   return MV_OK;
+}
+
+// ---- zero fill as a kernel (common.h: mvi_zero_async)
+namespace mv {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint32_t* __restrict__ p, size_t n32, size_t tail_bytes) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t n128 = n32 / 4;
+  u32x4* p4 = reinterpret_cast<u32x4*>(p);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n128; i += stride) p4[i] = u32x4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    const size_t i = n128 * 4 + threadIdx.x;
+    if (i < n32) p[i] = 0u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned char* b = reinterpret_cast<unsigned char*>(p) + n32 * 4;
+    for (size_t k = 0; k < tail_bytes; ++k) b[k] = 0;
+  }
+}
+}  // namespace mv
+
+hipError_t mvi_zero_async(void* p, size_t bytes, hipStream_t stream) {
+  if (!bytes) return hipSuccess;
+  if (((uintptr_t)p & 15) != 0) return hipMemsetAsync(p, 0, bytes, stream);      // (every caller passes 16-byte aligned buffers)
+  const size_t n32 = bytes / 4, tail = bytes % 4;
+  size_t blocks = (n32 / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mv::zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(p), n32, tail);
+  return hipGetLastError();
 }

@@ -187,6 +187,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// the same with the step count read from device memory (a captured HIP graph must not bake the host's count into its launch arguments)
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                        float wd, const int* __restrict__ step, float gscale) {
+  const float t = (float)(*step);
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gscale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * (mi / denom);
+    p[i] = pi;
+  }
+}
+
 // gather many gradient tensors (any storage type, given per tensor) into one flat fp32 buffer
 struct GatherDesc { const void* src; long dst_off; long n; int dtype; int pad; };
 __global__ __launch_bounds__(256) void multi_gather_kernel(const GatherDesc* __restrict__ descs, float* __restrict__ flat, int chunk) {
@@ -416,6 +434,15 @@ extern "C" int mv_adamw_flat(float* p, const float* g, float* m, float* v, long 
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2, grad_scale);
+  MV_LAUNCH_CHECK();
+  return MV_OK;
+}
+
+extern "C" int mv_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, const int* step_dev, float grad_scale, void* stream) {
+  MV_CHECK_ARG(p && g && m && v && n > 0 && step_dev);
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, weight_decay, step_dev, grad_scale);
   MV_LAUNCH_CHECK();
   return MV_OK;
 }

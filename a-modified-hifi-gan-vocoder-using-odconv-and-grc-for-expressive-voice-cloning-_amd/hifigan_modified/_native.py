@@ -89,6 +89,7 @@ def check(rc, name):
 
 
 _TRACE = bool(os.environ.get("MV_TRACE"))   # debugging aid: print every entry point and synchronise after it
+_CAPDBG = bool(os.environ.get("MV_CAPTURE_DEBUG"))   # debugging aid: name the first entry point after which a stream capture is dead
 
 
 def call(name, *args):
@@ -101,6 +102,14 @@ def call(name, *args):
         torch.cuda.synchronize()
         return
     check(fn(*args), name)
+    if _CAPDBG:
+        import sys
+        import torch
+        try:
+            torch.cuda.is_current_stream_capturing()
+        except Exception as e:      # noqa: BLE001
+            print(f"[mv] stream capture invalidated at or before {name}: {e}", file=sys.stderr, flush=True)
+            raise
 
 
 class MrfParams(ctypes.Structure):

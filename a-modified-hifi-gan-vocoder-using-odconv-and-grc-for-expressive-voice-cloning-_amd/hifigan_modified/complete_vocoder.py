@@ -12,6 +12,7 @@ reproduces that: the term is then identically zero).
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -100,7 +101,8 @@ class VocoderTrainer:
     device synchronisation a `.item()` costs."""
 
     def __init__(self, vocoder: ModifiedHiFiGANVocoder, generator_optimizer=None, discriminator_optimizer=None,
-                 device=None, mel_mode: str = "stft", grad_sync=None, bucket_mib: int = 8):
+                 device=None, mel_mode: str = "stft", grad_sync=None, bucket_mib: int = 8, use_graph: bool = False,
+                 graph_warmup: int = 2):
         device = device or torch.device("cuda")
         self.vocoder = vocoder.to(device)
         self.device = device
@@ -116,6 +118,12 @@ class VocoderTrainer:
         self.bucket_mib = bucket_mib
         self._overlap = {}
         self._d_params = list(self.vocoder.discriminators.parameters())
+        # use_graph: after `graph_warmup` eager steps at a given input signature the whole step (G forward, D step, G step, both
+        # AdamW launches, every weight re-pack) is captured into ONE HIP graph and replayed: the step is ~1000 launches, more than
+        # half of them shorter than the ~5 us it takes to issue one (single process, FlatAdamW optimizers only; static shapes)
+        self.use_graph = use_graph
+        self.graph_warmup = graph_warmup
+        self._graphs = {}
 
     @staticmethod
     def default_optimizers(vocoder, lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-4):
@@ -152,8 +160,11 @@ class VocoderTrainer:
                     self.grad_sync.start(flat)
                     scale = self.grad_sync.finish()
             opt.step(grad_scale=scale, gathered=True)
-            from . import disc_fused
-            disc_fused._packs.refresh_owned(opt)     # all conv packs of the stepped module in one launch
+            if not torch.cuda.is_current_stream_capturing():
+                from . import disc_fused
+                disc_fused._packs.refresh_owned(opt)     # all conv packs of the stepped module in one launch
+            # (captured step: each pack is recorded where the next forward misses its cache - the batched refresh would upload a new
+            #  pointer table from pageable memory, which a capture does not allow)
         else:
             loss.backward()
             if self.grad_sync:
@@ -170,6 +181,14 @@ class VocoderTrainer:
                    return_tensors: bool = False) -> Dict[str, float]:
         mel_spectrogram = mel_spectrogram.to(self.device)
         real_audio = real_audio.to(self.device)
+        if self.use_graph and self._graph_ok():
+            res = self._graph_step(mel_spectrogram, real_audio, speaker_embedding, emotion_embedding)
+        else:
+            res = self._step(mel_spectrogram, real_audio, speaker_embedding, emotion_embedding)
+        return res if return_tensors else self.to_floats(res)       # complete_vocoder.py:229-233 returns .item() floats
+
+    def _step(self, mel_spectrogram, real_audio, speaker_embedding, emotion_embedding):
+        """One step in the reference's order (complete_vocoder.py:207-226); returns device tensors."""
         out = self.vocoder(mel_spectrogram, speaker_embedding, emotion_embedding)
         fake_audio = out["generated_waveform"]
         # discriminator step on the detached fake
@@ -192,9 +211,78 @@ class VocoderTrainer:
             for p in self._d_params:
                 p.requires_grad_(True)
         self.last_losses = (g_losses, d_losses)
-        res = {"generator_loss": g_losses["total_loss"], "discriminator_loss": d_losses["total_loss"],
-               "mel_loss": g_losses["mel_loss"]}
-        return res if return_tensors else self.to_floats(res)       # complete_vocoder.py:229-233 returns .item() floats
+        return {"generator_loss": g_losses["total_loss"], "discriminator_loss": d_losses["total_loss"],
+                "mel_loss": g_losses["mel_loss"]}
+
+    # ---- captured step
+    def _graph_ok(self):
+        from .optim import FlatAdamW
+        import torch.distributed as dist
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        return single and not self.grad_sync and isinstance(self.generator_optimizer, FlatAdamW) and \
+            isinstance(self.discriminator_optimizer, FlatAdamW)
+
+    def _graph_step(self, mel, real, spk, emo):
+        sig = tuple((tuple(t.shape), t.dtype) if t is not None else None for t in (mel, real, spk, emo))
+        st = self._graphs.get(sig)
+        if st is None:
+            st = self._graphs[sig] = {"warm": 0, "graph": None}
+        # warm-up steps and the capture share ONE side stream: autograd pins every parameter's AccumulateGrad node to the stream it
+        # was first used on, and a node pinned to the default stream would pull the capture back onto it (and invalidate it)
+        if getattr(self, "_gstream", None) is None:
+            self._gstream = torch.cuda.Stream()
+        gs = self._gstream
+        if st["graph"] is None and st["warm"] < self.graph_warmup:
+            st["warm"] += 1                       # eager: packs weights, sets launch attributes, sizes every cache
+            gs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gs):
+                out = self._step(mel, real, spk, emo)
+            torch.cuda.current_stream().wait_stream(gs)
+            return out
+        gopt, dopt = self.generator_optimizer, self.discriminator_optimizer
+        if st["graph"] is None:
+            st["inputs"] = [None if t is None else t.to(self.device).clone() for t in (mel, real, spk, emo)]
+            self.last_losses = None               # (loss tensors keep last step's autograd graph alive)
+            # every cached cast / packed weight must MISS inside the capture: a hit bakes the pointer of a buffer that the replays never
+            # rewrite (the 16-bit discriminator heads: packed after the warm-up step's update, read again - stale - by every replay's
+            # discriminator step; D loss 1.2 % off from the second replay on), a miss records the pack kernel itself
+            from . import ops as _ops
+            _ops.bump_param_epoch()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            if os.environ.get("MV_GRAPH_DOT"):
+                graph.enable_debug_mode()
+            gopt.capture_begin()
+            dopt.capture_begin()
+            try:
+                with torch.cuda.graph(graph, stream=gs):
+                    st["out"] = self._step(*st["inputs"])
+                st["gstate"], st["dstate"] = gopt.capture_end(), dopt.capture_end()
+            except Exception:
+                gopt._capture = dopt._capture = None
+                self.use_graph = False            # this configuration cannot be captured: stay eager (and say so once)
+                raise
+            st["graph"] = graph
+            if os.environ.get("MV_GRAPH_DOT"):
+                graph.debug_dump(os.environ["MV_GRAPH_DOT"])
+        for dst, src in zip(st["inputs"], (mel, real, spk, emo)):
+            if dst is not None:
+                dst.copy_(src)
+        # replayed on the trainer's own stream, fenced against the caller's: on this ROCm build a ~1000-node graph replayed on a stream
+        # that also carries other eager training work between replays went wrong from its second replay on (MSD gradients, then NaN) -
+        # with the other work on a different stream, or nothing in between, it does not (tests/test_gpu_train_graph.py interleaves
+        # an eager trainer with a captured one)
+        if os.environ.get("MV_GRAPH_REPLAY_STREAM", "own") == "own":
+            cur = torch.cuda.current_stream()
+            gs.wait_stream(cur)
+            with torch.cuda.stream(gs):
+                st["graph"].replay()
+            cur.wait_stream(gs)
+        else:
+            st["graph"].replay()
+        dopt.after_replay(st["dstate"])
+        gopt.after_replay(st["gstate"])
+        return st["out"]
 
     @staticmethod
     def to_floats(losses):

@@ -13,6 +13,7 @@ from torch.autograd import Function
 
 from . import _native as N
 from . import ops
+from .ops import _zeros, _new_zeros
 
 _cache = ops._ParamCache()
 _ACT = {None: N.ACT_NONE, "none": N.ACT_NONE, "lrelu": N.ACT_LRELU, "tanh": N.ACT_TANH, "silu": N.ACT_SILU}
@@ -173,7 +174,7 @@ class _Conv1d(Function):
             if bias is not None:
                 bp = _w(bias, x)
                 if cop != Cout:                       # parameter-sized glue: bias zero-padded to the MFMA granule
-                    bp = torch.zeros(cop, device=x.device, dtype=x.dtype)
+                    bp = _zeros(cop, device=x.device, dtype=x.dtype)
                     bp[:Cout] = _w(bias, x)
             y_cl = ops.dconv_cl(x_cl, ops.dconv_pack(weight.reshape(Cout, Cin, 1, ks), x.dtype, 0, cop, cip), bp, cop, 1, ks, dilation)
             y = ops.ntc_to_nct(y_cl, Cout)
@@ -584,8 +585,8 @@ def _mrf_merged_branches(x, blk):
     wdt = folds[0][0].dtype
     src_w = torch.cat([f[0].reshape(-1) for f in folds] + [g.residual_proj.weight.reshape(-1).to(wdt) for g in gs])
     src_b = torch.cat([f[1].reshape(-1) for f in folds] + [g.residual_proj.bias.reshape(-1).to(wdt) for g in gs])
-    W = src_w.new_zeros(2 * nb * cpd * cin * kw).index_copy(0, idx_w, src_w).view(2 * nb * cpd, cin, kw)
-    bias = src_b.new_zeros(2 * nb * cpd).index_copy(0, idx_b, src_b)
+    W = _new_zeros(src_w, 2 * nb * cpd * cin * kw).index_copy(0, idx_w, src_w).view(2 * nb * cpd, cin, kw)
+    bias = _new_zeros(src_b, 2 * nb * cpd).index_copy(0, idx_b, src_b)
     u = conv1d(x, W, bias, padding=md)
     if all(g.norm_groups == gs[0].norm_groups and g.norm.eps == gs[0].norm.eps for g in gs):
         prm = []
@@ -632,7 +633,7 @@ def _grouped_residual_dense_weights(blk):
     cg = C // G
     wg = blk.grouped_conv.weight                                   # [C, C/G, k]
     M = blk.lora_alpha * (blk.lora_B @ blk.lora_A)                 # [C/G, C/G]
-    dense = wg.new_zeros(C, C, k)
+    dense = _new_zeros(wg, C, C, k)
     for gi in range(G):
         blkw = wg[gi * cg:(gi + 1) * cg].clone()
         blkw[:, :, k // 2] = blkw[:, :, k // 2] + M
@@ -663,7 +664,7 @@ def grouped_residual_conv1d(x, blk):
         h = ops.conv1d(x, _w(blk.grouped_conv.weight, x), _w(blk.grouped_conv.bias, x), None, 1, (k - 1) * d // 2, d, G)
         # u = h + alpha * lora: scale the (tiny) LoRA weight by alpha, accumulate onto h through `res`
         wl = ops.scale_shift(wl.view(1, 1, -1), ops.cast(blk.lora_alpha.detach(), x.dtype).view(1, 1),
-                             torch.zeros(1, 1, device=x.device, dtype=x.dtype)).view(C, C // G, 1)
+                             _zeros(1, 1, device=x.device, dtype=x.dtype)).view(C, C // G, 1)
         u = ops.conv1d(x, wl, None, None, 1, 0, 1, G, res=h)
         m = ops.conv1d(u, _w(blk.channel_mixer.weight, x), _w(blk.channel_mixer.bias, x), res=x)
         mean, rstd = ops.groupnorm_stats(m, G, blk.norm.eps)

@@ -11,6 +11,7 @@ import torch
 
 from . import _native as N
 from . import ops
+from .ops import _zeros, _new_zeros
 
 _INT3 = ctypes.c_int * 3
 
@@ -240,7 +241,7 @@ class OdconvFused:
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         B, _, Tout = g.shape
         rows = (Tin + 1) * stride
-        gp = torch.zeros(B, rows, cout, device=g.device, dtype=g.dtype)
+        gp = _zeros(B, rows, cout, device=g.device, dtype=g.dtype)
         N.call("mv_nct_to_ntc_window", c_void_p(g.data_ptr()), c_void_p(gp.data_ptr() + pad * cout * g.element_size()), B, cout, Tout,
                rows * cout, ops._dt(g), ops._stream())
         return gp
@@ -266,7 +267,7 @@ class OdconvFused:
         B, Tin, _ = x_cl.shape
         P = lambda t: c_void_p(t.data_ptr())
         gw = torch.empty(K, cin, cout, ks, device=x_cl.device, dtype=torch.float32)
-        galpha = torch.zeros(B, K, device=x_cl.device, dtype=torch.float32)
+        galpha = _zeros(B, K, device=x_cl.device, dtype=torch.float32)
         ws = torch.empty(N.lib().mv_odconvT_wgrad_workspace_bytes(B, cin, cout, ks, K, ops._dt(x_cl)), dtype=torch.uint8, device=x_cl.device)
         rc = N.lib().mv_odconvT_wgrad_mfma(P(x_cl), P(gp), P(wk), P(alpha), P(gw), P(galpha), P(ws), B, Tin, cin, cout, ks, stride, K,
                                            ops._dt(x_cl), ops._stream())

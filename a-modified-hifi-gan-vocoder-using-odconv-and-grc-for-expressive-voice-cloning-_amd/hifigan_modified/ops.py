@@ -328,6 +328,17 @@ def ntc_to_nct(x, c=None):
 
 
 # ------------------------------------------------------------------------------------------------ backward / training ops
+def _zeros(*shape, **kw):
+    """torch.zeros as a FILL KERNEL: torch.zeros (and hipMemsetAsync) become memset nodes under stream capture, and on this ROCm
+    build a replayed graph does not reliably order a memset node in front of the kernel node that follows it (common.h:
+    mvi_zero_async; found with a captured training step whose accumulating kernels started from stale buffers)."""
+    return torch.empty(*shape, **kw).fill_(0)
+
+
+def _new_zeros(t, *shape, **kw):
+    return t.new_empty(*shape, **kw).fill_(0)
+
+
 def _f32(*shape, device):
     return torch.empty(*shape, device=device, dtype=torch.float32)
 
@@ -388,7 +399,7 @@ def wgrad_cl_into(x_cl, g_cl, gw, gb, B, H, W, Cin, Cout, kh, kw, dil):
     key = (dev, torch.cuda.current_stream(dev).cuda_stream, n)
     ws = _WGRAD_WS.get(key)
     if ws is None:
-        ws = _WGRAD_WS[key] = torch.zeros(n, device=dev, dtype=torch.float32)
+        ws = _WGRAD_WS[key] = _zeros(n, device=dev, dtype=torch.float32)
     try:
         N.call("mv_dconv_wgrad_cl_pz", _p(x_cl), _p(g_cl), _p(gw), _p(gb), _p(ws), B, H, W, Cin, Cout, kh, kw, dil, _dt(x_cl), _stream())
     except Exception:
@@ -429,7 +440,7 @@ def conv1d_wgrad(x, gy, w, alpha, ks, stride, padding, dilation):
     assert x.stride(2) == 1 and gy.stride(2) == 1
     nb = 1 if alpha is None else alpha.shape[1]
     gw = _f32(*((nb, Cout, Cin, ks) if alpha is not None else (Cout, Cin, ks)), device=x.device)
-    galpha = torch.zeros(B, nb, device=x.device, dtype=torch.float32) if alpha is not None else None
+    galpha = _zeros(B, nb, device=x.device, dtype=torch.float32) if alpha is not None else None
     wsb = N.lib().mv_conv1d_wgrad_workspace_bytes(B, Cin, Cout, ks, nb)
     ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None
     N.call("mv_conv1d_wgrad", _p(x), _p(gy), _p(_c(w)) if w is not None else None, _p(alpha), _p(gw), _p(galpha), _p(ws),
@@ -550,9 +561,9 @@ class _ScalarArena:
 
     def take(self, device):
         if torch.cuda.is_current_stream_capturing():
-            return torch.zeros(1, device=device, dtype=torch.float32)
+            return _zeros(1, device=device, dtype=torch.float32)
         if self.buf is None or self.i >= self.buf.numel() or self.buf.device != device:
-            self.buf, self.i = torch.zeros(1024, device=device, dtype=torch.float32), 0
+            self.buf, self.i = _zeros(1024, device=device, dtype=torch.float32), 0
         v = self.buf[self.i:self.i + 1]
         self.i += 1
         return v
@@ -607,7 +618,7 @@ def mel_loss(wave, fb, target=None, n_fft=1024, hop=256, clampv=1e-5, weight=1.0
         raise ValueError("mel_loss: a loss (or its gradient) needs a target mel")
     acc = _scalars.take(wave.device)
     mel = _f32(B, n_mels, T // hop, device=wave.device) if want_mel else None
-    gwave = torch.zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None
+    gwave = _zeros(B, 1, T, device=wave.device, dtype=torch.float32) if backward else None
     if target is not None:
         target = cast(_c(target), torch.float32)
     N.call("mv_mel_loss", _p(wave), _p(fb), _p(target), _p(mel), _p(acc), _p(gwave), B, T, n_fft, hop, n_mels,

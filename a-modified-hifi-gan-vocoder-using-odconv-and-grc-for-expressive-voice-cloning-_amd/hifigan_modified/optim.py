@@ -46,7 +46,11 @@ class FlatAdamW:
                 view = self.flat_p[o:o + p.numel()].view(p.shape)
                 ops.copy_rows(p.detach().reshape(1, 1, -1), view.view(1, 1, -1))
                 p.data = view
-        self.step_count = 0
+        self.step_count = 0                  # optimizer steps taken (the largest per-parameter count)
+        self.steps = [0] * len(self.params)  # per parameter, like torch.optim.AdamW's state[p]['step']: a parameter whose .grad is None
+        #                                      in a step is left untouched, so its bias correction lags the others'
+        self._n_all = len(params)            # parameters a torch.optim optimizer would enumerate (param_groups[0]['params'])
+        self._capture = None                 # state of a captured training step (capture_begin / capture_end)
         # 16-bit shadows of the arena (one per activation dtype in use): refreshed by ONE cast launch per optimizer step, so
         # the ~200 per-parameter casts of a training step disappear; ops._ParamCache hands out views of them
         self._shadows = {}
@@ -76,11 +80,26 @@ class FlatAdamW:
                     g = g.contiguous()
                     p.grad = g
                 d["src"][i], d["dtype"][i] = g.data_ptr(), ops._DT[g.dtype]
-        table = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.flat_g.device, non_blocking=True)
+        table = self._upload(d)
         N.call("mv_multi_gather", c_void_p(table.data_ptr()), len(self.params), self._max_len,
                c_void_p(self.flat_g.data_ptr()), ops._stream())
         self._table = table   # keep alive until the launch has consumed it
         return self.flat_g
+
+    def _upload(self, descs):
+        """Descriptor table -> device.  Under stream capture the copy becomes a node of the HIP graph: its source is a pinned
+        host buffer that lives (unchanged) as long as the graph does - the gradient addresses it holds are the capture pool's, which
+        every replay reuses."""
+        raw = torch.from_numpy(descs.view(np.uint8).reshape(-1).copy())
+        cap = self._capture
+        if cap is not None:
+            if not cap["pinned"]:
+                raise RuntimeError("FlatAdamW: more gradient gathers in the captured step than capture_begin() prepared tables for")
+            pin = cap["pinned"].pop()           # pinned BEFORE the capture began (host allocations invalidate a capture)
+            pin[:raw.numel()].copy_(raw)
+            cap["keep"].append(pin)
+            return pin[:raw.numel()].to(self.flat_g.device, non_blocking=True)
+        return raw.to(self.flat_g.device, non_blocking=True)
 
     def gather_range(self, i0, i1):
         """Gather the gradients of parameters i0..i1-1 only (one launch): the per-bucket form used by
@@ -98,7 +117,7 @@ class FlatAdamW:
                     g = g.contiguous()
                     p.grad = g
                 d["src"][j], d["dtype"][j] = g.data_ptr(), ops._DT[g.dtype]
-        table = torch.from_numpy(d.view(np.uint8).reshape(-1)).to(self.flat_g.device, non_blocking=True)
+        table = self._upload(d)
         N.call("mv_multi_gather", c_void_p(table.data_ptr()), i1 - i0, int(d["n"].max()),
                c_void_p(self.flat_g.data_ptr()), ops._stream())
         self._tables = getattr(self, "_tables", [])[-64:] + [table]   # keep alive until the launches have consumed them
@@ -106,31 +125,84 @@ class FlatAdamW:
     def step(self, grad_scale=1.0, gathered=False):
         if not gathered:
             self.gather_grads()
-        self.step_count += 1
-        # torch.optim.AdamW leaves a parameter whose .grad is None untouched (no weight decay, no moment decay): update only the
-        # runs of parameters that received a gradient this step - one launch when all did, which is the usual case
-        hg = self._has_grad
-        runs = [(0, self.numel)]
-        if hg is not None and not all(hg):
-            runs, i, n = [], 0, len(self.params)
-            while i < n:
-                if hg[i]:
-                    j = i
-                    while j + 1 < n and hg[j + 1]:
-                        j += 1
-                    end = self.numel if j == n - 1 else self.offsets[j + 1]
-                    runs.append((self.offsets[i], end - self.offsets[i]))
-                    i = j + 1
-                else:
-                    i += 1
+        # torch.optim.AdamW leaves a parameter whose .grad is None untouched (no weight decay, no moment decay, no step): update only
+        # the runs of parameters that received a gradient this step and share a step count - one launch when all did, the usual case
+        hg = self._has_grad if self._has_grad is not None else [True] * len(self.params)
+        runs, i, n = [], 0, len(self.params)
+        while i < n:
+            if hg[i]:
+                j = i
+                while j + 1 < n and hg[j + 1] and self.steps[j + 1] == self.steps[i]:
+                    j += 1
+                end = self.numel if j == n - 1 else self.offsets[j + 1]
+                runs.append((i, j + 1, self.offsets[i], end - self.offsets[i]))
+                i = j + 1
+            else:
+                i += 1
         from .torch_ops import OPS
-        for off, cnt in runs:            # torch.ops.mi355x_vocoder.fused_adamw_ (in place on the arena slices; mv_adamw_flat)
-            OPS.fused_adamw_(self.flat_p[off:off + cnt], self.flat_g[off:off + cnt], self.exp_avg[off:off + cnt],
-                             self.exp_avg_sq[off:off + cnt], float(self.lr), float(self.betas[0]), float(self.betas[1]),
-                             float(self.eps), float(self.weight_decay), int(self.step_count), float(grad_scale))
+        cap = self._capture
+        for (i0, i1, off, cnt) in runs:   # torch.ops.mi355x_vocoder.fused_adamw_ (in place on the arena slices; mv_adamw_flat)
+            t = self.steps[i0] + 1
+            args = (self.flat_p[off:off + cnt], self.flat_g[off:off + cnt], self.exp_avg[off:off + cnt], self.exp_avg_sq[off:off + cnt],
+                    float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
+            if cap is None:
+                OPS.fused_adamw_(*args, int(t), float(grad_scale))
+                for k in range(i0, i1):
+                    self.steps[k] = t
+            else:
+                # being captured (nothing executes now): the count lives on the device and the graph itself advances it; the host's
+                # counts move in after_replay()
+                if len(cap["runs"]) >= len(cap["steps"]):
+                    raise RuntimeError("FlatAdamW: the captured step does not update the arena as one run per step count")
+                st = cap["steps"][len(cap["runs"])]
+                st.add_(1)
+                OPS.fused_adamw_dev_(*args, st, float(grad_scale))
+                cap["runs"].append((i0, i1))
+        self.step_count = max(self.steps)
         self._has_grad = None
         ops.bump_param_epoch(self)       # in-place arena update: cached casts / packed weights of THESE parameters must refresh
         self._refresh_shadows()
+
+    # ---- captured training steps (VocoderTrainer / HiFiGANTrainer with use_graph): everything the step launches is recorded once
+    def capture_begin(self):
+        """Call right before a training step is captured into a HIP graph (torch.cuda.graph): the gathers' descriptor tables become
+        pinned and persistent, and AdamW reads its step count from device tensors that the graph itself advances."""
+        dev = self.flat_p.device
+        planned = self._planned_runs()
+        # one device counter per run, set OUTSIDE the capture to the count the first replay starts from
+        steps = [torch.full((1,), self.steps[i0], dtype=torch.int32, device=dev) for (i0, _) in planned]
+        nbytes = self._descs.nbytes
+        pinned = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self._capture = {"keep": [], "steps": steps, "runs": [], "planned": planned, "pinned": pinned}
+
+    def _planned_runs(self):
+        """Runs of equal step count over ALL parameters (a captured step must give every parameter of the arena a gradient)."""
+        runs, i, n = [], 0, len(self.params)
+        while i < n:
+            j = i
+            while j + 1 < n and self.steps[j + 1] == self.steps[i]:
+                j += 1
+            runs.append((i, j + 1))
+            i = j + 1
+        return runs
+
+    def capture_end(self):
+        cap, self._capture = self._capture, None
+        if cap is None:
+            return None
+        if cap["runs"] != cap["planned"]:
+            raise RuntimeError("FlatAdamW: the captured step left parameters without a gradient: a captured step must update every "
+                               "parameter of the arena")
+        return {"keep": cap["keep"], "steps": cap["steps"], "runs": cap["runs"]}
+
+    def after_replay(self, state):
+        """Host-side bookkeeping after one replay of a captured step: step counts and cache epochs."""
+        for (i0, i1) in state["runs"]:
+            for k in range(i0, i1):
+                self.steps[k] += 1
+        self.step_count = max(self.steps)
+        ops.bump_param_epoch(self)
+        self._shadow_state = (self._state_epoch(), [p._version for p in self.params])   # the replay refreshed the shadows itself
 
     def _refresh_shadows(self):
         for dt, sh in self._shadows.items():
@@ -165,17 +237,19 @@ class FlatAdamW:
     def torch_state_dict(self):
         """The same state in torch.optim.AdamW's layout (what the reference's load path expects)."""
         state = {}
-        for p, o, ti in zip(self.params, self.offsets, self.torch_index):
-            state[ti] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
+        for k, (p, o, ti) in enumerate(zip(self.params, self.offsets, self.torch_index)):
+            if self.steps[k] == 0:
+                continue                      # torch creates a parameter's state at its first update
+            state[ti] = {"step": torch.tensor(float(self.steps[k])), "exp_avg": self.exp_avg[o:o + p.numel()].view(p.shape).clone(),
                          "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view(p.shape).clone()}
-        n_all = (max(self.torch_index) + 1) if self.torch_index else 0
+        n_all = self._n_all
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(n_all))}
         return {"state": state, "param_groups": [group]}
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        return {"step": self.step_count, "steps": list(self.steps), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
 
     def load_state_dict(self, sd):
@@ -188,9 +262,9 @@ class FlatAdamW:
             self.weight_decay = g0.get("weight_decay", self.weight_decay)
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
-            step = 0
+            self.steps = [0] * len(self.params)
             with torch.no_grad():
-                for p, o, ti in zip(self.params, self.offsets, self.torch_index):
+                for k, (p, o, ti) in enumerate(zip(self.params, self.offsets, self.torch_index)):
                     st = sd["state"].get(ti, sd["state"].get(str(ti)))
                     if st is None:
                         continue
@@ -198,10 +272,11 @@ class FlatAdamW:
                         raise ValueError(f"optimizer state {ti}: {tuple(st['exp_avg'].shape)} does not fit parameter {tuple(p.shape)}")
                     self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
-                    step = max(step, int(st["step"]))
-            self.step_count = step
+                    self.steps[k] = int(st["step"])
+            self.step_count = max(self.steps) if self.steps else 0
             return
         self.step_count = int(sd["step"])
+        self.steps = [int(x) for x in sd["steps"]] if "steps" in sd else [self.step_count] * len(self.params)
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

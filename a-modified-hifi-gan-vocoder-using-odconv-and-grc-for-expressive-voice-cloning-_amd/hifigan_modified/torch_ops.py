@@ -198,6 +198,22 @@ def _install():
     _LIB.impl("fused_adamw_", fused_adamw_, "CUDA")
     _LIB.impl("fused_adamw_", _refuse_cpu("fused_adamw_"), "CPU")
 
+    # the step count as a device tensor (int32, already incremented): what a captured training step replays
+    _LIB.define("fused_adamw_dev_(Tensor(a!) p, Tensor g, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, float beta2, "
+                "float eps, float weight_decay, Tensor step, float grad_scale) -> ()")
+
+    def fused_adamw_dev_(p, g, m, v, lr, b1, b2, eps, wd, step, gscale):
+        from ctypes import c_void_p
+        if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or \
+                any(t.dtype != torch.float32 or t.numel() != p.numel() for t in (p, g, m, v)):
+            raise RuntimeError(f"{NS}::fused_adamw_dev_: p, g, exp_avg, exp_avg_sq must be contiguous fp32 tensors of one size")
+        if step.dtype != torch.int32 or step.numel() != 1 or not step.is_cuda:
+            raise RuntimeError(f"{NS}::fused_adamw_dev_: step must be a one-element int32 GPU tensor")
+        N.call("mv_adamw_flat_dev", c_void_p(p.data_ptr()), c_void_p(g.data_ptr()), c_void_p(m.data_ptr()), c_void_p(v.data_ptr()),
+               p.numel(), float(lr), float(b1), float(b2), float(eps), float(wd), c_void_p(step.data_ptr()), float(gscale), ops._stream())
+    _LIB.impl("fused_adamw_dev_", fused_adamw_dev_, "CUDA")
+    _LIB.impl("fused_adamw_dev_", _refuse_cpu("fused_adamw_dev_"), "CPU")
+
 
 _install()
 OPS = torch.ops.mi355x_vocoder

@@ -254,6 +254,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5, help="timed training steps (0 = skip the training metric)")
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--train-eager", action="store_true", help="issue the training step eagerly instead of replaying its HIP graph")
+    ap.add_argument("--no-train-alt", action="store_true", help="skip the fp32 / fp16 activation legs of the training metric")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -547,38 +549,82 @@ def main():
     train = None
     if args.train_steps > 0:
         from hifigan_modified.parallel import broadcast_parameters
+
+        def train_leg(dtag, steps, warm, graph):
+            """K timed steps of VocoderTrainer (G forward, D step, G step, mel/STFT loss, both AdamW) at activation type `dtag`."""
+            tdt = getattr(torch, DT[dtag])
+            torch.manual_seed(0)
+            voc_ = H.ModifiedHiFiGANVocoder().to(dev)
+            if world > 1:
+                broadcast_parameters(voc_)
+            tr_ = H.VocoderTrainer(voc_, device=dev, use_graph=graph)       # grad_sync defaults to "overlap" when world > 1
+            torch.manual_seed(100 + rank)
+            tmel = torch.randn(B, 80, Tm, device=dev).to(tdt)
+            treal = torch.randn(B, 1, Tm * 256, device=dev).clamp(-1, 1).to(tdt)
+            tspk, temo = torch.randn(B, 192, device=dev).to(tdt), torch.randn(B, 384, device=dev).to(tdt)
+            torch.manual_seed(2 + rank)      # dropout stream of this rank
+            for _ in range(warm + (tr_.graph_warmup + 1 if graph else 0)):   # (graph: eager warm-up steps, the capture, then `warm` replays)
+                losses_ = tr_.train_step(tmel, treal, tspk, temo, return_tensors=True)
+            ovs_ = [o for o in (tr_.overlap_sync(tr_.generator_optimizer), tr_.overlap_sync(tr_.discriminator_optimizer)) if o is not None]
+            for o in ovs_:
+                o.timing, o.exposed_ms, o.reduced_bytes, o._ev = True, 0.0, 0, []
+            sync_all()
+            t0_ = time.perf_counter()
+            for _ in range(steps):
+                losses_ = tr_.train_step(tmel, treal, tspk, temo, return_tensors=True)
+            sync_all()
+            tel_ = time.perf_counter() - t0_
+            if world > 1:
+                t_ = torch.tensor([tel_], device=dev, dtype=torch.float64)
+                dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+                tel_ = float(t_.item())
+            return tel_, tr_.to_floats(losses_), ovs_, voc_, tr_
+
+        use_graph = world == 1 and not args.train_eager and not args.eager
         tdtype = getattr(torch, DT[args.train_dtype])
-        torch.manual_seed(0)
-        voc = H.ModifiedHiFiGANVocoder().to(dev)
-        if world > 1:
-            broadcast_parameters(voc)
-        trainer = H.VocoderTrainer(voc, device=dev)       # grad_sync defaults to "overlap" when world > 1
-        torch.manual_seed(100 + rank)
-        tmel = torch.randn(B, 80, Tm, device=dev).to(tdtype)
-        treal = torch.randn(B, 1, Tm * 256, device=dev).clamp(-1, 1).to(tdtype)
-        tspk, temo = torch.randn(B, 192, device=dev).to(tdtype), torch.randn(B, 384, device=dev).to(tdtype)
-        torch.manual_seed(2 + rank)      # dropout stream of this rank
-        for _ in range(args.train_warmup):
-            losses = trainer.train_step(tmel, treal, tspk, temo, return_tensors=True)
-        ovs = [o for o in (trainer.overlap_sync(trainer.generator_optimizer), trainer.overlap_sync(trainer.discriminator_optimizer)) if o is not None]
-        for o in ovs:
-            o.timing, o.exposed_ms, o.reduced_bytes, o._ev = True, 0.0, 0, []
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            losses = trainer.train_step(tmel, treal, tspk, temo, return_tensors=True)
-        sync_all()
-        tel = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([tel], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tel = float(t.item())
-        lf = trainer.to_floats(losses)
+        tel, lf, ovs, voc, trainer = train_leg(args.train_dtype, args.train_steps, args.train_warmup, use_graph)
+        coll = ("RCCL (torch.distributed 'nccl' backend over xGMI)" if backend == "nccl" else "torch.distributed '%s' backend (a rehearsal: NOT RCCL)" % backend)
         train = {"metric": "train audio-samples/s (G fwd + D step + G step + mel/STFT loss + AdamW)",
                  "value": round(B * Tm * 256 * world * args.train_steps / tel, 1), "unit": "samples/s",
                  "ms_per_step": round(tel / args.train_steps * 1e3, 2), "steps": args.train_steps, "dtype": args.train_dtype,
+                 "launch": "hipgraph (the whole step - ~1000 launches - captured after 2 eager steps and replayed)" if use_graph else "eager",
                  "global_batch": B * world, "losses_finite": all(x == x and abs(x) != float("inf") for x in lf.values()),
-                 "parallelism": ("dp%d, gradient buckets all-reduced over RCCL under the backward" % world) if world > 1 else "single GPU"}
+                 "parallelism": ("dp%d, gradient buckets all-reduced under the backward over %s" % (world, coll)) if world > 1 else "single GPU"}
+        if world > 1 and ovs:
+            # achieved all-reduce bandwidth, measured standalone on the generator's flat gradient buffer (the step's largest exchange)
+            buf = trainer.generator_optimizer.flat_g
+            for _ in range(3):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            e1.record()
+            torch.cuda.synchronize()
+            ar_ms = e0.elapsed_time(e1) / 10
+            train["allreduce_standalone"] = {"bytes": buf.numel() * 4, "ms": round(ar_ms, 4), "algbw_GBps": round(buf.numel() * 4 / ar_ms / 1e6, 1),
+                                             "busbw_GBps": round(buf.numel() * 4 / ar_ms / 1e6 * 2 * (world - 1) / world, 1), "backend": backend}
+        if rank == 0 and world == 1 and use_graph:
+            # the same step issued eagerly, and the other activation types (fp32 = split-operand kernels, fp16), beside the headline
+            del trainer
+            torch.cuda.empty_cache()
+            te, _, _, voc_e, tr_e = train_leg(args.train_dtype, max(2, args.train_steps // 2), 1, False)
+            train["eager_ms_per_step"] = round(te / max(2, args.train_steps // 2) * 1e3, 2)
+            del tr_e, voc_e
+            if not args.no_train_alt:
+                for alt in ("fp32", "fp16", "bf16"):
+                    if alt == args.train_dtype:
+                        continue
+                    torch.cuda.empty_cache()
+                    ta_, lfa, _, voc_a, tr_a = train_leg(alt, 3, 1, True)
+                    train["train_" + alt] = {"value": round(B * Tm * 256 * 3 / ta_, 1), "unit": "samples/s", "ms_per_step": round(ta_ / 3 * 1e3, 2),
+                                             "losses_finite": all(x == x and abs(x) != float("inf") for x in lfa.values())}
+                    del tr_a, voc_a
+                train["precision_note"] = ("activations in the named type, fp32 master weights / AdamW / weight gradients.  Small-model trajectories "
+                                           "(tests/test_gpu_train_graph.py): fp16 follows the fp32 run within 0.7 % (G) / 0.05 % (D) over the first "
+                                           "five steps and 6 % over twelve; bf16 3 % / 1 % and has left the fp32 trajectory by step 8")
+            torch.cuda.empty_cache()
         if ovs:
             exposed = sum(o.collect_timing() for o in ovs) / args.train_steps
             nbytes = sum(o.reduced_bytes for o in ovs) / args.train_steps

@@ -341,6 +341,9 @@ int mv_mel_loss(const void* wave, const float* fb, const float* target, float* m
 int mv_multi_gather(const void* descs_dev, int n_tensors, long max_len, float* flat, void* stream);
 int mv_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int step, float grad_scale, void* stream);
+/* the same with the step count (>= 1, already incremented) read from device memory: the form a captured HIP graph replays */
+int mv_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, const int* step_dev, float grad_scale, void* stream);
 /* uint8 keep-mask of nn.Dropout(p) (grc_lora.py:151,162): mask[i] = 1 with probability 1-p, Philox4x32-10 keyed by `seed`,
  * counter = element index / 8 (16 random bits per element; resolution 2^-16 on p). */
 int mv_dropout_mask(uint8_t* mask, long n, float p, long seed, void* stream);
