@@ -552,21 +552,12 @@ def grc_fold_bwd(g_weff, g_beff, conv_w, conv_b, lora_A, lora_B, lora_scaling, p
 
 
 class _ScalarArena:
-    """fp32 accumulators for the loss kernels: slots of one zero-filled block (one fill per 1024 losses instead of one per loss).
-    A slot is handed out once; the views keep their block alive.  Not used while a stream is being captured (a replay would not
-    re-zero the slots)."""
-
-    def __init__(self):
-        self.buf, self.i = None, 0
+    """fp32 accumulators for the loss kernels: one zeroed element each (a fill kernel: 16 bytes).  They used to be slots of one
+    zero-filled block; a loss returned by an operator is then a view at a non-zero storage offset, which a fake (meta) kernel cannot
+    reproduce (torch.library.opcheck), and a captured step needed fresh ones anyway."""
 
     def take(self, device):
-        if torch.cuda.is_current_stream_capturing():
-            return _zeros(1, device=device, dtype=torch.float32)
-        if self.buf is None or self.i >= self.buf.numel() or self.buf.device != device:
-            self.buf, self.i = _zeros(1024, device=device, dtype=torch.float32), 0
-        v = self.buf[self.i:self.i + 1]
-        self.i += 1
-        return v
+        return _zeros(1, device=device, dtype=torch.float32)
 
 
 _scalars = _ScalarArena()

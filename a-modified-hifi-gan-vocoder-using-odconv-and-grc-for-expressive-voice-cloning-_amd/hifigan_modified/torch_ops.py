@@ -90,7 +90,13 @@ def _register(name, schema, cls, pack, fmap):
     def impl(*args):
         rec = _Ctx()
         out = cls.forward(rec, *pack(*args))
-        _tls.last = (rec, out)
+        if torch.is_tensor(out) and any(torch.is_tensor(a) and a.data_ptr() == out.data_ptr() and a.numel() for a in args):
+            out = out.clone()        # the schema promises a fresh tensor (e.g. the MPD fold of a length that divides evenly is a view)
+        # the record is what setup_context (which runs right after this, in this thread, iff an input requires grad and grad mode is
+        # on) turns into the autograd context; when no argument requires a gradient nothing is kept alive.  (Grad mode itself cannot
+        # be asked here: the dispatcher runs this kernel below the autograd key with grad mode off.)
+        need = any(torch.is_tensor(a) and a.requires_grad for a in args)
+        _tls.last = (rec, out) if need else None
         return out
 
     _LIB.impl(name, impl, "CUDA")
@@ -99,7 +105,8 @@ def _register(name, schema, cls, pack, fmap):
     def setup(ctx, inputs, output):
         rec, out = getattr(_tls, "last", None) or (None, None)
         _tls.last = None
-        if rec is None or (torch.is_tensor(output) and tuple(out.shape) != tuple(output.shape)):
+        # paired by identity: the very storage the forward returned (not just a tensor of the same shape)
+        if rec is None or (torch.is_tensor(output) and (out.data_ptr() != output.data_ptr() or tuple(out.shape) != tuple(output.shape))):
             raise RuntimeError(f"{NS}::{name}: forward record does not belong to this call")
         ctx.mv_attrs = {k: v for k, v in rec.__dict__.items() if k not in ("saved_tensors", "needs_input_grad")}
         ctx.mv_nsaved = len(rec.saved_tensors)
@@ -215,5 +222,87 @@ def _install():
     _LIB.impl("fused_adamw_dev_", _refuse_cpu("fused_adamw_dev_"), "CPU")
 
 
+def _install_fakes():
+    """Shape / dtype functions (torch.library.register_fake): FakeTensor tracing (torch.compile, torch.export, opcheck) sees through
+    every operator without running a kernel.  Formulas = the reference modules' (nn.Conv1d / ConvTranspose1d / AvgPool1d output sizes,
+    discriminators.py:72-79 for the fold)."""
+    fake = lambda name: torch.library.register_fake(f"{NS}::{name}", lib=_LIB)
+
+    @fake("odconv1d")
+    def _(x, kernels, bias, att_w, att_b, stride, padding, output_padding, dilation, act, slope, fused):
+        ks = kernels.shape[3]
+        return x.new_empty(x.shape[0], kernels.shape[1], (x.shape[2] + 2 * padding - dilation * (ks - 1) - 1) // stride + 1)
+
+    @fake("odconv_transpose1d")
+    def _(x, kernels, bias, att_w, att_b, stride, padding, output_padding, dilation, act, slope, fused):
+        ks = kernels.shape[3]
+        return x.new_empty(x.shape[0], kernels.shape[2], (x.shape[2] - 1) * stride - 2 * padding + dilation * (ks - 1) + output_padding + 1)
+
+    @fake("odconv_attn")
+    def _(x, att_w, att_b):
+        return x.new_empty(x.shape[0], att_w.shape[0], dtype=torch.float32)
+
+    @fake("conv1d")
+    def _(x, weight, bias, stride, padding, dilation, groups, act, slope):
+        ks = weight.shape[2]
+        return x.new_empty(x.shape[0], weight.shape[0], (x.shape[2] + 2 * padding - dilation * (ks - 1) - 1) // stride + 1)
+
+    @fake("conv2d")
+    def _(x, weight, bias, pad_h, pad_w, act, slope):
+        return x.new_empty(x.shape[0], weight.shape[0], x.shape[2] + 2 * pad_h - weight.shape[2] + 1, x.shape[3] + 2 * pad_w - weight.shape[3] + 1)
+
+    @fake("group_norm")
+    def _(x, weight, bias, res, mask, groups, eps, act, slope, mask_scale):
+        return torch.empty_like(x)
+
+    @fake("film")
+    def _(x, cond, proj_w, proj_b, feature_dim):
+        return torch.empty_like(x)
+
+    @fake("avg_pool1d")
+    def _(x, scale):
+        return x.new_empty(x.shape[0], x.shape[1], x.shape[2] // scale)
+
+    @fake("mpd_fold")
+    def _(x, period):
+        return x.new_empty(x.shape[0], x.shape[1], period, (x.shape[2] + period - 1) // period)
+
+    def _stack(x, slope, *params):
+        return x.new_empty((x.shape[0], 1) + tuple(x.shape[2:]))
+    torch.library.register_fake(f"{NS}::disc_conv_stack", _stack, lib=_LIB)
+
+    @fake("gan_loss")
+    def _(x, y, kind, c, weight):
+        return x.new_empty((), dtype=torch.float32)
+
+    @fake("mel_loss")
+    def _(wave, target, fb, n_fft, hop, clampv, weight, kind):
+        return wave.new_empty((), dtype=torch.float32)
+
+    @fake("mel_spectrogram")
+    def _(wave, fb, n_fft, hop, clampv):
+        return wave.new_empty(wave.shape[0], fb.shape[0], wave.shape[-1] // hop, dtype=torch.float32)
+
+    @fake("grc_mrf_block")
+    def _(x, handle):
+        return torch.empty_like(x)
+
+    @fake("generator_forward")
+    def _(mel, speaker_emb, emotion_emb, handle):
+        total = 1
+        for f in _obj(handle).gen.upsample_factors:
+            total *= f
+        return mel.new_empty(mel.shape[0], 1, mel.shape[2] * total)
+
+    @fake("fused_adamw_")
+    def _(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale):
+        return None
+
+    @fake("fused_adamw_dev_")
+    def _(p, g, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale):
+        return None
+
+
 _install()
+_install_fakes()
 OPS = torch.ops.mi355x_vocoder

@@ -110,3 +110,51 @@ def test_operator_path_equals_direct_function_path(H, dtype):
         # weight-gradient kernels accumulate with float atomics: equal to rounding, everything else bit for bit
         assert torch.equal(a, b) or (a.float() - b.float()).abs().max() <= 1e-5 * max(1.0, float(b.float().abs().max()))
     assert torch.equal(res["torch_ops"][0], res["direct"][0])
+
+
+def test_opcheck_every_differentiable_operator(H):
+    """torch.library.opcheck on each operator with small real inputs: the schema is honest (no undeclared aliasing or mutation), the
+    autograd registration is a proper autograd-key kernel, and the fake kernel's output metadata equals the real kernel's.  (The AOT
+    dispatch test is left out: Python-side cache objects cross the dispatcher as integer handles, which a traced graph may carry but
+    cannot re-create.)"""
+    from torch.library import opcheck
+    from hifigan_modified import functional as Fn
+    ns = torch.ops.mi355x_vocoder
+    tests = ("test_schema", "test_autograd_registration", "test_faketensor")
+    g = lambda *s: torch.randn(*s, device="cuda", requires_grad=True)
+    c = lambda *s: torch.randn(*s, device="cuda")
+    opcheck(ns.odconv1d, (g(2, 16, 24), g(4, 8, 16, 3), g(4, 8), g(4, 16, 1), g(4), 1, 1, 0, 1, 0, 0.1, 0), test_utils=tests)
+    opcheck(ns.odconv_transpose1d, (g(2, 16, 10), g(4, 16, 8, 8), g(4, 8), g(4, 16, 1), g(4), 4, 2, 0, 1, 1, 0.1, 0), test_utils=tests)
+    opcheck(ns.odconv_attn, (c(2, 16, 24), c(4, 16, 1), c(4)), test_utils=tests)
+    opcheck(ns.conv1d, (g(2, 8, 40), g(12, 8, 3), g(12), 1, 1, 1, 1, 1, 0.1), test_utils=tests)
+    opcheck(ns.conv2d, (g(2, 4, 3, 40), g(8, 4, 3, 3), g(8), 1, 1, 1, 0.1), test_utils=tests)
+    opcheck(ns.group_norm, (g(2, 8, 40), g(8), g(8), None, None, 2, 1e-5, 3, 0.1, 1.0), test_utils=tests)
+    opcheck(ns.film, (g(2, 8, 5), g(2, 16), g(16, 16), g(16), 8), test_utils=tests)
+    opcheck(ns.avg_pool1d, (g(2, 1, 101), 4), test_utils=tests)
+    opcheck(ns.mpd_fold, (g(2, 1, 100), 3), test_utils=tests)
+    opcheck(ns.mpd_fold, (g(2, 1, 100), 2), test_utils=tests)            # divides evenly: must still be a fresh tensor
+    opcheck(ns.gan_loss, (g(2, 1, 50), c(2, 1, 50), 1, 0.0, 10.0), test_utils=tests)
+    opcheck(ns.gan_loss, (g(2, 1, 50), None, 0, 1.0, 1.0), test_utils=tests)
+    from hifigan_modified.mel import mel_filterbank
+    fb = mel_filterbank(22050, 1024, 80).cuda()
+    opcheck(ns.mel_loss, (g(2, 1, 2048), c(2, 80, 8), fb, 1024, 256, 1e-5, 45.0, 0), test_utils=tests)
+    opcheck(ns.mel_spectrogram, (c(2, 1, 2048), fb, 1024, 256, 1e-5), test_utils=tests)
+    p_, g_, m_, v_ = c(64), c(64), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    opcheck(ns.fused_adamw_, (p_, g_, m_, v_, 1e-3, 0.9, 0.999, 1e-8, 0.01, 1, 1.0), test_utils=("test_schema", "test_faketensor"))
+    opcheck(ns.fused_adamw_dev_, (p_, g_, m_, v_, 1e-3, 0.9, 0.999, 1e-8, 0.01, torch.ones(1, dtype=torch.int32, device="cuda"), 1.0),
+            test_utils=("test_schema", "test_faketensor"))
+
+
+def test_forward_record_is_dropped_without_a_gradient_and_paired_by_identity(H):
+    """The forward -> setup_context hand-off (torch_ops.py): a no-grad call leaves nothing behind (it used to keep x, alpha, the
+    pooled sums and the output alive until the next operator call), and a record is only accepted for the tensor it produced."""
+    from hifigan_modified import torch_ops
+    ns = torch.ops.mi355x_vocoder
+    x = torch.randn(2, 8, 40, device="cuda")
+    w = torch.randn(12, 8, 3, device="cuda")
+    ns.conv1d(x, w, None, 1, 1, 1, 1, 0, 0.1)                     # nothing requires grad (the whole inference path)
+    assert getattr(torch_ops._tls, "last", None) is None
+    y = ns.conv1d(x.requires_grad_(True), w, None, 1, 1, 1, 1, 0, 0.1)
+    assert getattr(torch_ops._tls, "last", None) is None           # consumed by setup_context
+    y.sum().backward()
+    assert x.grad is not None and x.grad.shape == x.shape

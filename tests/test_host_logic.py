@@ -154,6 +154,39 @@ def test_torch_library_operators_are_registered_and_refuse_cpu_tensors():
         ns.avg_pool1d(torch.randn(1, 1, 8), 2)
 
 
+def test_operators_have_fake_kernels_with_the_reference_shapes():
+    """register_fake for every operator: FakeTensor tracing needs no GPU and reproduces the output sizes of the reference's modules
+    (nn.Conv1d / nn.ConvTranspose1d inside odconv.py:89-106,187-204, nn.AvgPool1d discriminators.py:94, the fold :72-79)."""
+    import hifigan_modified  # noqa: F401
+    from hifigan_modified import torch_ops  # noqa: F401
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    ns = torch.ops.mi355x_vocoder
+    dev = "cuda" if torch.cuda.is_available() else "meta"
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        e = lambda *s, **k: torch.empty(*s, device="cuda", **k)
+        for (cin, cout, ks, stride, pad, dil, T) in ((16, 8, 3, 1, 2, 2, 24), (80, 64, 7, 1, 3, 1, 32), (8, 8, 5, 2, 2, 1, 31)):
+            y = ns.odconv1d(e(2, cin, T), e(4, cout, cin, ks), e(4, cout), e(4, cin, 1), e(4), stride, pad, 0, dil, 0, 0.1, 0)
+            assert tuple(y.shape) == tuple(torch.nn.Conv1d(cin, cout, ks, stride, pad, dil)(torch.empty(2, cin, T, device="meta")).shape)
+            y = ns.conv1d(e(2, cin, T), e(cout, cin, ks), None, stride, pad, dil, 1, 0, 0.1)
+            assert tuple(y.shape) == tuple(torch.nn.Conv1d(cin, cout, ks, stride, pad, dil, device="meta")(torch.empty(2, cin, T, device="meta")).shape)
+        for (cin, cout, ks, stride, pad, opad, T) in ((16, 8, 16, 8, 4, 0, 10), (8, 8, 4, 2, 1, 0, 33), (8, 4, 6, 3, 1, 1, 10)):
+            y = ns.odconv_transpose1d(e(2, cin, T), e(4, cin, cout, ks), e(4, cout), e(4, cin, 1), e(4), stride, pad, opad, 1, 1, 0.1, 0)
+            ref = torch.nn.ConvTranspose1d(cin, cout, ks, stride, pad, opad, device="meta")(torch.empty(2, cin, T, device="meta"))
+            assert tuple(y.shape) == tuple(ref.shape)
+        assert tuple(ns.conv2d(e(2, 32, 3, 100), e(64, 32, 3, 3), e(64), 1, 1, 1, 0.1).shape) == (2, 64, 3, 100)
+        assert tuple(ns.avg_pool1d(e(2, 1, 1001), 4).shape) == (2, 1, 250)
+        for P, T in ((2, 8192), (3, 1000), (11, 8192)):
+            assert tuple(ns.mpd_fold(e(2, 1, T), P).shape) == (2, 1, P, -(-T // P))
+        assert ns.odconv_attn(e(3, 16, 9, dtype=torch.bfloat16), e(4, 16, 1), e(4)).dtype == torch.float32
+        assert tuple(ns.mel_spectrogram(e(2, 1, 2048), e(80, 513), 1024, 256, 1e-5).shape) == (2, 80, 8)
+        assert ns.gan_loss(e(2, 1, 50), None, 0, 1.0, 1.0).shape == () and ns.mel_loss(e(2, 1, 2048), e(2, 80, 8), e(80, 513), 1024, 256, 1e-5, 45.0, 0).shape == ()
+        x = e(2, 64, 100, dtype=torch.float16)
+        assert ns.group_norm(x, e(64), e(64), None, None, 8, 1e-5, 0, 0.1, 1.0).dtype == torch.float16
+        assert tuple(ns.film(e(2, 512, 5), e(2, 64), e(128, 64), e(128), 64).shape) == (2, 512, 5)
+        ws = [e(32, 1, 3, 3), e(32), e(64, 32, 3, 3), e(64), e(128, 64, 3, 3), e(128), e(256, 128, 3, 3), e(256), e(1, 256, 3, 3), e(1)]
+        assert tuple(ns.disc_conv_stack(e(2, 1, 3, 334), 0.1, *ws).shape) == (2, 1, 3, 334)
+
+
 def test_mixed_precision_switch_is_host_state_only():
     """set_mixed_precision only records the split point; it validates its arguments and does not touch parameters."""
     import hifigan_modified as H
