@@ -103,6 +103,8 @@ class OverlappedGradSync:
         self._need = [e - a for a, e, _, _ in self.buckets]
         self._have = [0] * len(self.buckets)
         self._launched = [True] * len(self.buckets)     # nothing armed until begin()
+        self._next = -1
+        self._lazy = set()
         self._works = []
         self._armed = False
         self.timing = timing
@@ -122,14 +124,22 @@ class OverlappedGradSync:
                 return
             b = self._bucket_of[i]
             self._have[b] += 1
-            if self._have[b] == self._need[b] and not self._launched[b]:
-                self._launch(b)
+            # Collectives must be issued in the SAME order on every rank.  Gradients arrive roughly from the last parameter to the
+            # first, so the order is fixed as descending bucket index: a complete bucket is launched only once every higher-index
+            # bucket has been (whatever order the hooks fire in on this rank, the sequence of all-reduces is the same everywhere).
+            # (Buckets that were still incomplete at finish() of the previous step - parameters without a gradient - are not waited
+            #  for: they go last, in finish(); every rank runs the same model, so every rank skips the same ones.)
+            while self._next >= 0 and (self._next in self._lazy or self._have[self._next] == self._need[self._next]):
+                if self._next not in self._lazy:
+                    self._launch(self._next)
+                self._next -= 1
         return hook
 
     def begin(self):
         """Arm the hooks for the next backward of this parameter group."""
         self._have = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
         self._works = []
         self._armed = True
 
@@ -143,9 +153,11 @@ class OverlappedGradSync:
 
     def finish(self):
         self._armed = False
-        for b in range(len(self.buckets)):
+        self._lazy = {b for b in range(len(self.buckets)) if self._have[b] < self._need[b]}
+        for b in range(len(self.buckets) - 1, -1, -1):          # the rest, in the same descending order
             if not self._launched[b]:
                 self._launch(b)
+        self._next = -1
         if self._works:
             if self.timing and torch.cuda.is_available():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -104,6 +104,16 @@ def _overlap_worker(rank, world, port, q):
     order = []
     orig = sync._launch
     sync._launch = lambda b: (order.append(b), orig(b))[1]
+    # step 1: launches go in one fixed (descending) order, so the gradient-less last bucket holds everything back until finish(),
+    # which learns that this bucket never completes; from step 2 on it is skipped during the backward and goes last
+    sync.begin()
+    ((net(x) - y) ** 2).mean().backward()
+    assert order == [], order
+    sync.finish()
+    assert order == [6, 5, 4, 3, 2, 1, 0], order
+    for p in net.parameters():
+        p.grad = None
+    order.clear()
     sync.begin()
     ((net(x) - y) ** 2).mean().backward()
     launched_in_backward = list(order)
@@ -115,8 +125,8 @@ def _overlap_worker(rank, world, port, q):
 
 
 def test_overlapped_bucket_allreduce_gloo_world2():
-    """OverlappedGradSync: buckets are launched from grad-ready hooks DURING the backward (last layer first), the rest in
-    finish(); the reduced buffer is the mean of the two ranks' gradients; a gradient-less parameter contributes zeros."""
+    """OverlappedGradSync: buckets are launched from grad-ready hooks DURING the backward, always in descending bucket order
+    (the same on every rank, whatever order the hooks fire in), the rest in finish(); the reduced buffer is the mean of the two ranks' gradients; a gradient-less parameter contributes zeros."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
