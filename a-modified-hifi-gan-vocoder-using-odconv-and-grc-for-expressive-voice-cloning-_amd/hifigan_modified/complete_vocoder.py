@@ -291,8 +291,9 @@ class VocoderTrainer:
 
     def save_checkpoint(self, path: str):
         torch.save({"vocoder_state_dict": self.vocoder.state_dict(),
-                    "generator_optimizer_state_dict": self.generator_optimizer.state_dict(),
-                    "discriminator_optimizer_state_dict": self.discriminator_optimizer.state_dict()}, path)
+                    # torch.optim.AdamW's layout, so the reference's own load path (complete_vocoder.py:463-468) reads the file too
+                    "generator_optimizer_state_dict": self.generator_optimizer.torch_state_dict(),
+                    "discriminator_optimizer_state_dict": self.discriminator_optimizer.torch_state_dict()}, path)
 
     def load_checkpoint(self, path: str):
         ck = torch.load(path, map_location=self.device, weights_only=True)

@@ -151,4 +151,4 @@ class HiFiGANTrainer:
 
     def save_checkpoint(self, path, epoch, loss):
         torch.save({"epoch": epoch, "model_state_dict": self.model.state_dict(),
-                    "optimizer_state_dict": self.optimizer.state_dict(), "loss": loss}, path)
+                    "optimizer_state_dict": self.optimizer.torch_state_dict(), "loss": loss}, path)   # torch.optim.AdamW's layout

@@ -120,6 +120,12 @@ class ModifiedHiFiGANGenerator(nn.Module):
             if through not in names or dtype not in (torch.float16, torch.bfloat16):
                 raise ValueError(f"through must be one of {names} (or None), dtype fp16 / bf16")
             mixed = (names.index(through), dtype)
+            if (self.mel_channels, self.upsample_factors) != (80, [8, 8, 2, 2]):
+                import warnings
+                warnings.warn("set_mixed_precision: the error budget behind this mix (DESIGN.md section 5) was measured on the 80-mel "
+                              f"[8, 8, 2, 2] generator only; on {self.mel_channels}-mel {self.upsample_factors} (the 48 kHz geometry: every "
+                              "sub-fp32 mix simulated above 1e-3 waveform rel-L2) check the output against fp32 storage before using it",
+                              stacklevel=2)
         object.__setattr__(self, "_mv_mixed", mixed)
         return self
 

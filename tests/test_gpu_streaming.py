@@ -151,6 +151,11 @@ def test_vocoder_trainer_checkpoint_resumes_identically(H, tmp_path):
     a.save_checkpoint(path)
     ck = torch.load(path, map_location="cpu", weights_only=True)
     assert set(ck) == {"vocoder_state_dict", "generator_optimizer_state_dict", "discriminator_optimizer_state_dict"}
+    # the optimizer entries are in torch.optim.AdamW's own layout: the reference's load path (complete_vocoder.py:463-468) takes them
+    for key, mod in (("generator_optimizer_state_dict", a.vocoder.generator), ("discriminator_optimizer_state_dict", a.vocoder.discriminators)):
+        topt = torch.optim.AdamW([torch.nn.Parameter(p.detach().cpu().clone()) for p in mod.parameters()], lr=2e-4, betas=(0.8, 0.99), weight_decay=1e-4)
+        topt.load_state_dict(ck[key])
+        assert len(topt.state) > 0 and all(float(st["step"]) == 1.0 for st in topt.state.values())
     b = make()
     b.load_checkpoint(path)
     # the restored state is bit-identical: weights, AdamW moments, step counters
@@ -195,6 +200,9 @@ def test_hifigan_trainer_variant_a_steps_and_checkpoints(H, tmp_path, dtype):
     tr.save_checkpoint(path, epoch=3, loss=total)
     ck = torch.load(path, map_location="cpu", weights_only=True)
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"} and ck["epoch"] == 3
+    topt = torch.optim.AdamW([torch.nn.Parameter(p.detach().float().cpu().clone()) for p in model.parameters()], lr=2e-4)
+    topt.load_state_dict(ck["optimizer_state_dict"])              # torch.optim.AdamW's layout (conditioned_hifigan.py:292-299)
+    assert len(topt.state) > 0 and all(float(st["step"]) == 2.0 for st in topt.state.values())
 
 
 def test_pack_cache_follows_each_optimizer_separately():

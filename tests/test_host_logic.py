@@ -201,4 +201,11 @@ def test_mixed_precision_switch_is_host_state_only():
     with pytest.raises(ValueError):
         g.set_mixed_precision("up0", torch.float32)
     assert g.set_mixed_precision(None).mixed_precision is None
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")              # the validated geometry does not warn ...
+        g.set_mixed_precision("up1", mrf_weights="fp16").set_mixed_precision(None)
+    g48 = H.ModifiedHiFiGANGenerator(mel_channels=128, hidden_channels=64, upsample_factors=[8, 8, 4, 2])
+    with pytest.warns(UserWarning, match="48 kHz"):  # ... the 48 kHz one (no sub-fp32 mix inside 1e-3: DESIGN.md section 5) does
+        g48.set_mixed_precision("up1")
     assert all(torch.equal(v, before[k]) for k, v in g.state_dict().items()) and set(g.state_dict()) == set(before)
