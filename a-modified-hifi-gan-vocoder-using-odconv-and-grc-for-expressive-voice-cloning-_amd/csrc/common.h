@@ -21,6 +21,16 @@ template <> __device__ __forceinline__ float ld<bf16>(const bf16* p) {
   return __uint_as_float(((uint32_t)(*reinterpret_cast<const uint16_t*>(p))) << 16);
 }
 template <> __device__ __forceinline__ float ld<f16>(const f16* p) { return (float)(*p); }
+// A load whose conversion - its first use, i.e. the wait for it - is deliberately placed later: the raw bits, zero-extended to one
+// 32-bit register (16-bit values kept in a `T` array get packed in pairs right behind the loads, which is a use as well).
+template <typename T> __device__ __forceinline__ uint32_t ldraw(const T* p);
+template <> __device__ __forceinline__ uint32_t ldraw<float>(const float* p) { return *reinterpret_cast<const uint32_t*>(p); }
+template <> __device__ __forceinline__ uint32_t ldraw<bf16>(const bf16* p) { return *reinterpret_cast<const uint16_t*>(p); }
+template <> __device__ __forceinline__ uint32_t ldraw<f16>(const f16* p) { return *reinterpret_cast<const uint16_t*>(p); }
+template <typename T> __device__ __forceinline__ float rawtofl(uint32_t r);
+template <> __device__ __forceinline__ float rawtofl<float>(uint32_t r) { return __uint_as_float(r); }
+template <> __device__ __forceinline__ float rawtofl<bf16>(uint32_t r) { return __uint_as_float(r << 16); }
+template <> __device__ __forceinline__ float rawtofl<f16>(uint32_t r) { return (float)__builtin_bit_cast(f16, (uint16_t)r); }
 
 template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }

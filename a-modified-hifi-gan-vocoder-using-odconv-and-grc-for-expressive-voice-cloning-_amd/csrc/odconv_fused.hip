@@ -37,6 +37,9 @@ struct OdP {
   int film_F;
   int pool_n;     // floats per sample in pooled_in: slots * rows partial sums of the producing launch (Cin = dense sums)
   int in_f16;     // fp32 launch whose INPUT x is fp16 (mixed storage: the first fp32 stage reads the fp16 stream; multi-tile kernel only)
+#ifdef MV_OD_TIMING
+  int dbg;        // ablation switches of the timing build (MV_KL_DBG)
+#endif
 };
 
 template <typename T> struct WLoad;   // this lane's 8 packed weights -> fp32
@@ -124,20 +127,23 @@ constexpr int OD_LU = 8;                                   // 64-channel slices 
 // depend on nothing, so the partial sums, their reduction and these loads are ONE memory round trip instead of three in a row (in-kernel
 // marks: partial sums 1.5 k, logits 3-6 k - a weight round trip, then the bias loaded after the wave tree - and softmax 2.5 k ticks).
 template <typename T>
-__device__ __forceinline__ bool od_logits_preload(float (&wv)[2][OD_LU], float (&bv)[2], int S, const OdP& p,
+__device__ __forceinline__ bool od_logits_preload(uint32_t (&wv)[2][OD_LU], uint32_t (&bv)[2], int S, const OdP& p,
                                                   const T* __restrict__ att_w, const T* __restrict__ att_b) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int Cin = p.Cin, npair = S * p.K;
   if (npair > 8 || Cin > 64 * OD_LU) return false;
+  // every load unconditional at a clamped address and kept RAW (storage type): `cc < Cin ? ld(...) : 0` compiles to a branch per load
+  // with an s_waitcnt vmcnt(0) inside - 18 memory round trips in a row (15 k of the first upsampler's 25 k prologue ticks) - and a
+  // conversion here would be the loads' first use, i.e. a wait for them before the caller's own loads are issued
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int pr = wid * 2 + q < npair ? wid * 2 + q : npair - 1, kb = pr % p.K;
 #pragma unroll
     for (int u = 0; u < OD_LU; ++u) {
       const int cc = 64 * u + lane;
-      wv[q][u] = cc < Cin ? ld<T>(att_w + (long)kb * Cin + cc) : 0.f;
+      wv[q][u] = ldraw<T>(att_w + (long)kb * Cin + (cc < Cin ? cc : Cin - 1));
     }
-    bv[q] = att_b ? ld<T>(att_b + kb) : 0.f;
+    bv[q] = ldraw<T>(att_b ? att_b + kb : att_w);
   }
   return true;
 }
@@ -145,7 +151,7 @@ __device__ __forceinline__ bool od_logits_preload(float (&wv)[2][OD_LU], float (
 template <typename T>
 __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int sstride, int S, const OdP& p,
                                           const T* __restrict__ att_w, const T* __restrict__ att_b,
-                                          const float (*pre)[OD_LU] = nullptr, const float* preb = nullptr) {
+                                          const uint32_t (*pre)[OD_LU] = nullptr, const uint32_t* preb = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int Cin = p.Cin, npair = S * p.K;
   constexpr int U = OD_LU;                                 // 64-channel slices per batch
@@ -158,16 +164,19 @@ __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int cc = 64 * u + lane;
-        if (cc < Cin) acc[q] += pre[q][u] * scratch[s * sstride + cc];
+        const float m = scratch[s * sstride + (cc < Cin ? cc : Cin - 1)];     // (the weights of cc >= Cin are zeros)
+        acc[q] += cc < Cin ? rawtofl<T>(pre[q][u]) * m : 0.f;
       }
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const float v = wave_sum(acc[q]);
       const int pr = pr0 + q;
+      uint32_t rb = preb[q];
+      asm volatile("" : "+v"(rb));                         // (keeps the conversion - the wait for the preloads - down here)
       if (lane == 0 && pr < npair) {
         const int s = pr / p.K, kb = pr % p.K;
-        alds[s * OD_MAXK + kb] = v / (float)p.Tin + preb[q];
+        alds[s * OD_MAXK + kb] = v / (float)p.Tin + (att_b ? rawtofl<T>(rb) : 0.f);
       }
     }
     return;
@@ -182,7 +191,7 @@ __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cc = c0 + 64 * u + lane;
-          wv[q][u] = cc < Cin ? ld<T>(att_w + (long)kb * Cin + cc) : 0.f;
+          wv[q][u] = ld<T>(att_w + (long)kb * Cin + (cc < Cin ? cc : Cin - 1));      // (unconditional: see od_logits_preload)
         }
       }
 #pragma unroll
@@ -191,7 +200,8 @@ __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int cc = c0 + 64 * u + lane;
-          if (cc < Cin) acc[q] += wv[q][u] * scratch[s * sstride + cc];
+          const float m = scratch[s * sstride + (cc < Cin ? cc : Cin - 1)];
+          acc[q] += cc < Cin ? wv[q][u] * m : 0.f;
         }
       }
     }
@@ -217,25 +227,46 @@ __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int
 template <typename T>
 __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scratch, int S, int b0, const OdP& p,
                                                        const float* __restrict__ pooled_in, const T* __restrict__ att_w,
-                                                       const T* __restrict__ att_b) {
+                                                       const T* __restrict__ att_b, long long* tm = nullptr) {
   const int tid = threadIdx.x;
   const int Cin = p.Cin;
   const int npc = p.pool_n / Cin;                       // partials per channel
-  float wpre[2][OD_LU], bpre[2];
+  uint32_t wpre[2][OD_LU], bpre[2];
   const bool havew = od_logits_preload<T>(wpre, bpre, S, p, att_w, att_b);
   if (Cin <= 256) {
     const int G = 256 / Cin, c = tid % Cin, gq = tid / Cin;          // Cin is a multiple of 8; threads beyond G * Cin idle
-    for (int s = 0; s < S; ++s) {
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      if (gq < G && b0 + s < p.B) {
-        const float* src = pooled_in + (long)(b0 + s) * p.pool_n + c;
-        int j = gq;
-        for (; j + 3 * G < npc; j += 4 * G) {
-          a0 += src[(long)j * Cin]; a1 += src[(long)(j + G) * Cin]; a2 += src[(long)(j + 2 * G) * Cin]; a3 += src[(long)(j + 3 * G) * Cin];
-        }
-        for (; j < npc; j += G) a0 += src[(long)j * Cin];
+    // two samples per sweep: their loads are independent and issued together (a sample after the other is a memory round trip each)
+    for (int s0 = 0; s0 < S; s0 += 2) {
+      float a[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      bool ok[2];
+      const float* src[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        ok[q] = gq < G && s0 + q < S && b0 + s0 + q < p.B;
+        src[q] = pooled_in + (long)(ok[q] ? b0 + s0 + q : b0) * p.pool_n + c;
       }
-      if (gq < G) scratch[(s * G + gq) * Cin + c] = (a0 + a1) + (a2 + a3);
+      int j = gq;
+      for (; j + 3 * G < npc; j += 4 * G) {
+        float v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[q][i] = ok[q] ? src[q][(long)(j + i * G) * Cin] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) a[q][i] += v[q][i];
+      }
+      for (; j < npc; j += G) {
+        float v[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v[q] = ok[q] ? src[q][(long)j * Cin] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q][0] += v[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (gq < G && s0 + q < S) scratch[((s0 + q) * G + gq) * Cin + c] = (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
     }
     __syncthreads();
     for (int i = tid; i < S * Cin; i += 256) {            // fixed-order sum over the G groups -> scratch[s][0][c]
@@ -247,24 +278,39 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
     __syncthreads();
     od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
   } else {
-    // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel; a thread owns channels tid, tid + 256, ...
-    for (int s = 0; s < S; ++s)
-      for (int c = tid; c < Cin; c += 256) {
-        float a = 0.f;
-        if (b0 + s < p.B) {
-          const float* src = pooled_in + (long)(b0 + s) * p.pool_n + c;
-          int j = 0;
-          for (; j + 3 < npc; j += 4) {                  // four independent loads in flight, added in index order
-            const float v0 = src[(long)j * Cin], v1 = src[(long)(j + 1) * Cin], v2 = src[(long)(j + 2) * Cin], v3 = src[(long)(j + 3) * Cin];
-            a += v0; a += v1; a += v2; a += v3;
-          }
-          for (; j < npc; ++j) a += src[(long)j * Cin];
-        }
-        scratch[s * Cin + c] = a;                        // needs S * Cin floats of scratch
+    // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel.  Thread t owns the (sample, channel) elements
+    // t, t + 256, ... of [S][Cin], four at a time with their loads issued together: partial j of all four, added in index order.
+    // (A `for (s) for (c)` loop with the load inside is one dependent memory round trip per element and thread: 4 x ~4.5 k ticks at
+    // the first upsampler, where this prologue was 25 k of the kernel's 80 k ticks.)
+    const int E = S * Cin;
+    for (int u0 = 0; u0 < E; u0 += 1024) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* src[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = u0 + tid + 256 * u;
+        const int s = idx / Cin, cc = idx - s * Cin;
+        ok[u] = idx < E && b0 + s < p.B;
+        src[u] = pooled_in + (long)(ok[u] ? b0 + s : b0) * p.pool_n + (ok[u] ? cc : 0);
       }
+      for (int j = 0; j < npc; ++j) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ok[u] ? src[u][(long)j * Cin] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] += v[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u0 + tid + 256 * u < E) scratch[u0 + tid + 256 * u] = a[u];       // [s][Cin]: needs S * Cin floats of scratch
+    }
+    if (tm) tm[0] = clock64();
     __syncthreads();
+    if (tm) tm[1] = clock64();
     od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
   }
+  if (tm) tm[2] = clock64();
   __syncthreads();
   if (tid < S) {                                          // softmax over the banks, values in registers (one LDS round trip, not 3 K)
     float z[OD_MAXK], m = -INFINITY, den = 0.f;
@@ -901,7 +947,8 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
   constexpr int LES = 2;                           // operand element size in LDS (fp32 storage: hi / lo bf16 planes)
   extern __shared__ __align__(16) char lds[];
   float* alds = reinterpret_cast<float*>(lds);
-  char* xl = reinterpret_cast<char*>(alds + S * OD_MAXK);
+  float* ascr = alds + S * OD_MAXK;                // scratch of the attention prologue: its own region, so that it runs under the staging
+  char* xl = reinterpret_cast<char*>(ascr + S * (p.Cin > 256 ? p.Cin : 256));
   const int PLANE = p.Cin * LES;                   // byte offset of the lo plane inside a row (SPLIT)
   const int RS = lds_row_stride(SPLIT ? 2 * PLANE : p.Cin * ES, LES);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -915,15 +962,51 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
 #endif
   OD_TM();
 
+  // ---- 16-bit storage: the whole (short) input of the S samples goes to LDS by LDS-DMA, one 1 KB piece of a row per instruction, all
+  // of them issued before anything else (no register round trip, no wait between batches); rows outside the sample and the zero row
+  // fail the buffer range check and arrive as zeros.  In-kernel marks of the register-staged form at the first upsampler: attention
+  // prologue 25.5 k ticks, THEN staging 14.1 k (three dependent batches), main loop 32.6 k, epilogue 8.4 k.
+  constexpr bool XDMA = !SPLIT;
+#ifdef MV_OD_TIMING
+  const int kdbg = p.dbg;
+#else
+  constexpr int kdbg = 0;
+#endif
+  if (XDMA && !(kdbg & 1)) {
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int RB = p.Cin * ES;                     // bytes of one row
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const long xbytes = (long)p.B * p.Tin * RB;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)), 0,
+                                                                         (int)(xbytes < 0x7fffffffL ? xbytes : 0x7fffffffL), 0x00020000);
+    const int npc = (RB + 1023) >> 10;
+    for (int i = wu; i < S * p.nrows; i += 4) {
+      const int s = i / p.nrows, r = i - s * p.nrows;
+      const int tin = p.shift_lo + r;
+      const bool ok = r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin;
+      const unsigned gbase = ok ? (unsigned)(((long)(b0 + s) * p.Tin + tin) * RB) : 0x7ffffff0u;      // (host: B * Tin * RB < 2^31 - 16 K)
+      for (int pc = 0; pc < npc; ++pc)
+        if (pc * 1024 + lane * 16 < RB)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(xl + i * RS + pc * 1024), 16, gbase + pc * 1024 + lane * 16, 0, 0, 0);
+    }
+  }
   // ---- alpha (odconv.py:36-40)
   if (alpha_in) {
     if (tid < S * p.K) {
       const int s = tid / p.K, kb = tid % p.K;
       alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
     }
+  } else if (kdbg & 2) {
+    if (tid < S * p.K) alds[(tid / p.K) * OD_MAXK + tid % p.K] = 0.25f;
+    OD_TM(); OD_TM(); OD_TM(); OD_TM();
   } else {
-    od_alpha_from_partials<T>(alds, reinterpret_cast<float*>(xl), S, b0, p, pooled_in, att_w, att_b);   // xl: not staged yet
-    __syncthreads();                                   // the scratch is dead before the x tiles land in it
+#ifdef MV_OD_TIMING
+    OD_TM();
+    od_alpha_from_partials<T>(alds, ascr, S, b0, p, pooled_in, att_w, att_b, tmk + ntm);
+    ntm += 3;
+#else
+    od_alpha_from_partials<T>(alds, ascr, S, b0, p, pooled_in, att_w, att_b);
+#endif
   }
   OD_TM();
   // ---- stage the whole (short) input of every sample: row r <-> input step r + shift_lo, last row = zeros
@@ -958,17 +1041,9 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
             *reinterpret_cast<u32x2*>(xl + d[u] + PLANE) = lo;
           }
       }
-    } else {
-      stage_batched<8, 256>(tid, S * per, xl, [&](int i, const void*& src, int& dst) {
-        const int s = i / per, rem = i - s * per;
-        const int r = rem / cpr, ch = rem - r * cpr;
-        const int tin = p.shift_lo + r;
-        if (r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin)
-          src = reinterpret_cast<const char*>(x + ((long)(b0 + s) * p.Tin + tin) * p.Cin) + ch * 16;
-        dst = (s * p.nrows + r) * RS + ch * 16;
-      });
     }
   }
+  if constexpr (XDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   OD_TM();
 
@@ -1185,8 +1260,8 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
   p.nrows = p.Tin - p.shift_lo + 1;
   const size_t xbytes = (size_t)S * p.nrows * lds_row_stride(M::ES == 4 ? 4 * p.Cin : p.Cin * M::ES, 2);
   const size_t obytes = (size_t)S * NB * 16 * (64 * MW * M::ES + 16);
-  const size_t lds = sizeof(float) * (S * OD_MAXK) + (xbytes > obytes ? xbytes : obytes);
-  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * (S * OD_MAXK + S * (p.Cin > 256 ? p.Cin : 256)) + (xbytes > obytes ? xbytes : obytes);
+  if (lds > 160 * 1024 || (long)p.B * p.Tin * p.Cin * M::ES > 0x7fff0000L) return MV_ERR_UNSUPPORTED;
   auto kern = odconv_kloop_kernel<T, S, NB, 4, MW>;
   static size_t lds_set = 0;
   if (lds > lds_set) {
@@ -1201,6 +1276,7 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
   static int calls = 0;
   if (!dbg) { hipMalloc(&dbg, 8192 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(od_dbg), &dbg, sizeof(dbg)); }
   hipMemsetAsync(dbg, 0xff, 8192 * 8 * 8, stream);
+  { const char* e = getenv("MV_KL_DBG"); p.dbg = e ? atoi(e) : 0; }
 #endif
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
                      (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p);
@@ -1212,7 +1288,7 @@ static int od_kloop_launch(const void* x, const void* wp, const void* bias, cons
     const long nwg = (long)grid.x * grid.y < 8192 ? (long)grid.x * grid.y : 8192;
     double avg[8] = {0}; int cnt[8] = {0};
     for (long w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) { long long v = hbuf[w * 8 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
-    fprintf(stderr, "[kloop timing] S %d MW %d grid %u x %u marks (start, alpha, -, staged, loop, end):", S, MW, grid.x, grid.y);
+    fprintf(stderr, "[kloop timing] S %d MW %d grid %u x %u marks (start, dma issued, sums, barrier, logits, alpha, staged, loop | end):", S, MW, grid.x, grid.y);
     for (int i = 0; i < 8; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
     fprintf(stderr, "\n");
   }
