@@ -1,6 +1,7 @@
 // Shared device helpers for the MI355X (gfx950) vocoder kernels.
 // Storage types: float, bf16, fp16; arithmetic/accumulation is always fp32.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
@@ -21,6 +22,14 @@ template <> __device__ __forceinline__ float ld<bf16>(const bf16* p) {
   return __uint_as_float(((uint32_t)(*reinterpret_cast<const uint16_t*>(p))) << 16);
 }
 template <> __device__ __forceinline__ float ld<f16>(const f16* p) { return (float)(*p); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence pair around s_barrier, and on gfx9 loads and
+// stores share one counter: hipcc emits `s_waitcnt vmcnt(0)` in front of every barrier, so a global prefetch issued before the barrier
+// (the next tile's rows, the next k-steps' weight fragments) is waited for right there and overlaps nothing - in-kernel marks of the
+// multi-tile ODConv kernel: 14.7 k ticks per tile "staging" a tile that had been requested a whole tile earlier.  Use this one where the
+// barrier only separates LDS writers from LDS readers; global loads stay in flight across it (their own uses are still waited for by
+// the compiler), global stores are not made visible to the other waves by it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // A load whose conversion - its first use, i.e. the wait for it - is deliberately placed later: the raw bits, zero-extended to one
 // 32-bit register (16-bit values kept in a `T` array get packed in pairs right behind the loads, which is a use as well).
 template <typename T> __device__ __forceinline__ uint32_t ldraw(const T* p);
@@ -46,6 +55,29 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+// Four wave sums at once on the DPP path (no LDS round trips: __shfl_xor is ds_bpermute, ~100 cycles a step): quad butterfly, half-row
+// and row mirrors give every lane its 16-lane row total, the four row totals are read with v_readlane and added in a fixed order.
+// Every lane returns the same bits.
+__device__ __forceinline__ void wave_sum4_dpp(float (&v)[4]) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+  };
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp(v[i], std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp(v[i], std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp(v[i], std::integral_constant<int, 0x141>{});     // row_half_mirror
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] += dpp(v[i], std::integral_constant<int, 0x140>{});     // row_mirror
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = __builtin_bit_cast(int, v[i]);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    v[i] = (r0 + r1) + (r2 + r3);
+  }
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -151,11 +151,11 @@ __device__ __forceinline__ bool od_logits_preload(uint32_t (&wv)[2][OD_LU], uint
 template <typename T>
 __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int sstride, int S, const OdP& p,
                                           const T* __restrict__ att_w, const T* __restrict__ att_b,
-                                          const uint32_t (*pre)[OD_LU] = nullptr, const uint32_t* preb = nullptr) {
+                                          bool have, const uint32_t (&pre)[2][OD_LU], const uint32_t (&preb)[2]) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int Cin = p.Cin, npair = S * p.K;
   constexpr int U = OD_LU;                                 // 64-channel slices per batch
-  if (pre) {                                               // npair <= 8, Cin <= 512: one batch, weights already in registers
+  if (have) {                                              // npair <= 8, Cin <= 512: one batch, weights already in registers
     const int pr0 = wid * 2;
     float acc[2] = {0.f, 0.f};
 #pragma unroll
@@ -224,15 +224,60 @@ __device__ __forceinline__ void od_logits(float* alds, const float* scratch, int
 // the G group sums and then the K logits are added in a fixed order, so the result does not depend on timing (no atomics).
 // (One wave per (sample, bank) walking pool_n elements with a dependent load per step cost 7-12 us per layer: a chain of
 // pool_n / 64 L2 round trips in front of everything else.)  `scratch` = >= S * 256 floats of LDS that nothing else uses yet.
-template <typename T>
+template <typename T, int NTHR = 256>                     // NTHR: threads of the workgroup (those past 256 only take part in the logits)
 __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scratch, int S, int b0, const OdP& p,
                                                        const float* __restrict__ pooled_in, const T* __restrict__ att_w,
                                                        const T* __restrict__ att_b, long long* tm = nullptr) {
   const int tid = threadIdx.x;
   const int Cin = p.Cin;
   const int npc = p.pool_n / Cin;                       // partials per channel
-  uint32_t wpre[2][OD_LU], bpre[2];
-  const bool havew = od_logits_preload<T>(wpre, bpre, S, p, att_w, att_b);
+  // Fast tail (K <= 4 banks, Cin <= 512, a wave per sample): wave s holds ALL of sample s's attention weights (raw, requested here -
+  // they depend on nothing), forms the K logits with one DPP reduction and the softmax in registers.  The general tail below goes
+  // through (sample, bank) pairs, an LDS tree per pair, a barrier and a softmax thread: 6 k ticks behind the partial sums at the first
+  // upsampler, against ~1.5 k here.
+  const int wid_ = tid >> 6, lane_ = tid & 63;
+  const bool fast = p.K <= 4 && Cin <= 64 * OD_LU && S <= NTHR / 64;
+  uint32_t wq[4][OD_LU], bq[4];
+  if (fast && wid_ < S) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int kb = k < p.K ? k : 0;
+#pragma unroll
+      for (int u = 0; u < OD_LU; ++u) {
+        const int cc = 64 * u + lane_;
+        wq[k][u] = ldraw<T>(att_w + (long)kb * Cin + (cc < Cin ? cc : Cin - 1));
+      }
+      bq[k] = ldraw<T>(att_b ? att_b + kb : att_w);
+    }
+  }
+  auto fast_tail = [&](int sstride) {
+    if (wid_ < S) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < OD_LU; ++u) {
+        const int cc = 64 * u + lane_;
+        const float m = scratch[wid_ * sstride + (cc < Cin ? cc : Cin - 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += cc < Cin ? rawtofl<T>(wq[k][u]) * m : 0.f;
+      }
+      wave_sum4_dpp(acc);
+      float z[4], mx = -INFINITY, den = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        z[k] = k < p.K ? acc[k] / (float)p.Tin + (att_b ? rawtofl<T>(bq[k]) : 0.f) : -INFINITY;
+        mx = fmaxf(mx, z[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { z[k] = k < p.K ? expf(z[k] - mx) : 0.f; den += z[k]; }
+      if (lane_ == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < p.K) alds[wid_ * OD_MAXK + k] = z[k] / den;
+      }
+    }
+  };
+  uint32_t wpre[2][OD_LU] = {}, bpre[2] = {};
+  bool havew = false;
+  if (!fast) havew = od_logits_preload<T>(wpre, bpre, S, p, att_w, att_b);
   if (Cin <= 256) {
     const int G = 256 / Cin, c = tid % Cin, gq = tid / Cin;          // Cin is a multiple of 8; threads beyond G * Cin idle
     // two samples per sweep: their loads are independent and issued together (a sample after the other is a memory round trip each)
@@ -269,14 +314,15 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
         if (gq < G && s0 + q < S) scratch[((s0 + q) * G + gq) * Cin + c] = (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
     }
     __syncthreads();
-    for (int i = tid; i < S * Cin; i += 256) {            // fixed-order sum over the G groups -> scratch[s][0][c]
+    for (int i = tid; i < S * Cin; i += NTHR) {           // fixed-order sum over the G groups -> scratch[s][0][c]
       const int s = i / Cin, cc = i - s * Cin;
       float a = 0.f;
       for (int q = 0; q < G; ++q) a += scratch[(s * G + q) * Cin + cc];
       scratch[(s * G) * Cin + cc] = a;
     }
     __syncthreads();
-    od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
+    if (fast) { fast_tail(G * Cin); return; }
+    od_logits<T>(alds, scratch, G * Cin, S, p, att_w, att_b, havew, wpre, bpre);
   } else {
     // wide inputs (Cin > 256, e.g. the first upsampler's 512): few partials per channel.  Thread t owns the (sample, channel) elements
     // t, t + 256, ... of [S][Cin], four at a time with their loads issued together: partial j of all four, added in index order.
@@ -291,7 +337,7 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
       for (int u = 0; u < 4; ++u) {
         const int idx = u0 + tid + 256 * u;
         const int s = idx / Cin, cc = idx - s * Cin;
-        ok[u] = idx < E && b0 + s < p.B;
+        ok[u] = idx < E && b0 + s < p.B && tid < 256;
         src[u] = pooled_in + (long)(ok[u] ? b0 + s : b0) * p.pool_n + (ok[u] ? cc : 0);
       }
       for (int j = 0; j < npc; ++j) {
@@ -303,12 +349,13 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (u0 + tid + 256 * u < E) scratch[u0 + tid + 256 * u] = a[u];       // [s][Cin]: needs S * Cin floats of scratch
+        if (u0 + tid + 256 * u < E && tid < 256) scratch[u0 + tid + 256 * u] = a[u];       // [s][Cin]: needs S * Cin floats of scratch
     }
     if (tm) tm[0] = clock64();
     __syncthreads();
     if (tm) tm[1] = clock64();
-    od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b, havew ? wpre : nullptr, bpre);
+    if (fast) { fast_tail(Cin); if (tm) tm[2] = clock64(); return; }
+    od_logits<T>(alds, scratch, Cin, S, p, att_w, att_b, havew, wpre, bpre);
   }
   if (tm) tm[2] = clock64();
   __syncthreads();
@@ -897,6 +944,190 @@ static int od_mt_launch(const void* x, const void* wp, const void* bias, const f
   if (slots_out) { *slots_out = (int)grid.x; return MV_OK; }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const TI*)x, (const T*)wp, (const T*)bias, alpha,
                      pooled_in, (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p, TL);
+  return MV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ sample-resident variant
+// Second upsampler (ODConvTranspose1d 256 -> 128, ks = 2 * stride, 257 columns per sample, 4 x 1 MB of banks), 16-bit storage.
+// The multi-tile kernel above keeps a wave's 16 MIXED fragments resident and walks 96-column tiles: per tile it re-stages a 50 KB x
+// tile through registers, crosses four barriers and reads every B fragment from LDS once per 16 rows; ablations put its 33 us at
+// 16 us of prologue (attention chain + bank mix) + 17 us for three tiles whose matrix work is 1.5 k cycles per wave each.
+// Here the WHOLE sample is resident instead: one workgroup = one sample x 128 GEMM rows (8 waves x 16 rows; with 128 output
+// channels that is one phase r of the stride, i.e. complete 256-byte output rows), the sample's 258 input rows (t = -1 .. Tin) go
+// to LDS once by LDS-DMA while the attention chain runs, and a wave then streams its 16 k-steps: mix the k-step's four bank
+// fragments (ring of RD k-steps in flight, started before anything else) into ONE A operand, use it against all 17 column tiles,
+// drop it.  No barrier after the prologue, no resident mixed fragments (the registers hold 17 accumulator tiles and the ring).
+// The loop is LDS-bound by construction - every B fragment is read once per 16 rows: 8 waves x 17 KB per k-step.
+template <typename T, int CIN, int NT>
+__global__ __launch_bounds__(512) void odconv_sample_kernel(const T* __restrict__ x, const T* __restrict__ wp, const T* __restrict__ bias,
+                                                            const float* __restrict__ alpha_in, const float* __restrict__ pooled_in,
+                                                            const T* __restrict__ att_w, const T* __restrict__ att_b, T* __restrict__ y,
+                                                            float* __restrict__ pooled_out, OdP p) {
+  using M = Mma<T>;
+  using V = typename M::V;
+  using WL = WLoad<T>;
+  constexpr int ES = 2, KB = 4, KST = 2 * CIN / 32, KPT = CIN / 32, RB = CIN * ES, RD = 4;
+  static_assert(M::ES == 2 && KST % RD == 0 && RB <= 1024, "16-bit storage, static ring slots, one DMA instruction per row");
+  extern __shared__ __align__(16) char lds[];
+  float* alds = reinterpret_cast<float*>(lds);                 // [OD_MAXK]
+  float* ascr = alds + OD_MAXK;                                // scratch of the attention chain: [max(Cin, 256)]
+  char* xl = reinterpret_cast<char*>(ascr + (CIN > 256 ? CIN : 256));
+  const int RS = lds_row_stride(RB, 2);
+  const int tid = threadIdx.x, lane = tid & 63, col = lane & 15, g = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y, n_mt = p.M / 16;
+  const int mt = blockIdx.x * 8 + wid;                         // this wave's M-tile (host: M % 128 == 0)
+  const int nrows = p.nq + 1;                                  // input steps shift_lo .. Tin (the first and the last are zeros)
+#ifdef MV_OD_TIMING
+  long long tmk[8]; int ntm = 0;
+#endif
+  OD_TM();
+
+  // ---- bank fragments of the first RD k-steps: they depend on nothing
+  const long bank_stride = (long)n_mt * KST * 512 * ES;
+  const char* wlane = reinterpret_cast<const char*>(wp) + ((long)mt * KST * 512 + lane * 8) * ES;
+  typename WL::R ring[RD][KB];
+  auto ldring = [&](int ks, int slot) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) ring[slot][kb] = WL::load(wlane + (long)ks * 512 * ES + (kb < p.K ? kb : 0) * bank_stride);
+  };
+#pragma unroll
+  for (int i = 0; i < RD; ++i) ldring(i, i);
+  // ---- the sample's rows -> LDS (rows outside the sample fail the buffer range check and arrive as zeros)
+  {
+    typedef __attribute__((address_space(3))) void lds_void;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) + (long)b * p.Tin * RB, 0, p.Tin * RB, 0x00020000);
+    for (int i = wid; i < nrows; i += 8) {
+      const int tin = p.shift_lo + i;
+      const unsigned gbase = (tin >= 0 && tin < p.Tin) ? (unsigned)(tin * RB) : 0x7ffffff0u;
+      if (lane * 16 < RB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(xl + i * RS), 16, gbase + lane * 16, 0, 0, 0);
+    }
+  }
+  OD_TM();
+  // ---- alpha (odconv.py:36-40)
+  if (alpha_in) {
+    if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+  } else {
+    od_alpha_from_partials<T, 512>(alds, ascr, 1, b, p, pooled_in, att_w, att_b);
+  }
+  OD_TM();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  OD_TM();
+  float al[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) al[kb] = kb < p.K ? alds[kb] : 0.f;
+
+  const int row = 16 * mt + 4 * g;
+  const int r = row / p.Cout, o = row - r * p.Cout;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};                          // alpha-mixed bias of this lane's 4 channels (requested before the loop)
+  if (bias) {
+    float braw[KB][4];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) M::load4(bias + (long)(kb < p.K ? kb : 0) * p.Cout + o, braw[kb]);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] += al[kb] * braw[kb][i];
+  }
+  // per-lane LDS byte offset of column tile n, tap 1 (input step q - 1 = row q); tap 0 is one row further.  Columns past nq are
+  // computed on clamped rows and never stored.
+  unsigned lb[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    int r = n * 16 + col;
+    r = r < nrows - 2 ? r : nrows - 2;
+    lb[n] = (unsigned)(r * RS + g * 16);
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KST; ++ks) {
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) WL::fma8(ring[ks % RD][kb], al[kb], f);
+    const V a = make_a<T>(f);
+    if (ks + RD < KST) ldring(ks + RD, ks % RD);
+    const int tap = ks / KPT;                                  // k-chunk 4 ks + g = tap * Cin/8 + c8
+    const int koff = (tap ? 0 : RS) + (ks % KPT) * 64;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = M::mma(a, M::load_b(xl + lb[n] + koff), acc[n]);
+  }
+
+  OD_TM();
+  // ---- epilogue: bias, activation, 8-byte stores (a lane's 4 rows are 4 consecutive channels), channel sums for the next layer
+  const ActLrelu actf{p.act == ACT_NONE ? 1.f : p.slope};
+  float psum[4] = {0.f, 0.f, 0.f, 0.f};
+  T* yb = y + (long)b * p.Tout * p.Cout + o;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int q = n * 16 + col;
+    const int u = q * p.stride + r - p.pad;
+    const bool ok = q < p.nq && u >= 0 && u < p.Tout;
+    float ov[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ov[i] = actf(acc[n][i] + bv[i]);
+      psum[i] += ok ? M::round_store(ov[i]) : 0.f;
+    }
+    if (ok) M::store4(yb + (long)u * p.Cout, ov);
+  }
+  if (pooled_out) {                                            // one workgroup covers the sample's columns: one slot
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = psum[i];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+      psum[i] = v;
+    }
+    if (col == 0) *reinterpret_cast<f32x4*>(pooled_out + (long)b * p.M + row) = f32x4{psum[0], psum[1], psum[2], psum[3]};
+  }
+#ifdef MV_OD_TIMING
+  OD_TM();
+  if (tid == 0 && od_dbg) {
+    const long wgid = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wgid < 8192) for (int i = 0; i < 8; ++i) od_dbg[wgid * 8 + i] = i < ntm ? tmk[i] - tmk[0] : -1;
+  }
+#endif
+}
+
+template <typename T, int CIN, int NT>
+static int od_sample_launch(const void* x, const void* wp, const void* bias, const float* alpha, const float* pooled_in, const void* att_w,
+                            const void* att_b, void* y, float* pooled_out, OdP p, hipStream_t stream, int* slots_out) {
+  if (!p.transposed || p.ntaps != 2 || p.K > 4 || p.Cin != CIN || p.M % 128 || p.nq > NT * 16 || p.nq <= (NT - 1) * 16 ||
+      p.shift_lo != -1 || p.act > ACT_LRELU || (long)p.Tin * CIN * 2 > 0x7fff0000L)
+    return MV_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(float) * (OD_MAXK + (CIN > 256 ? CIN : 256)) + (size_t)(p.nq + 1) * lds_row_stride(CIN * 2, 2);
+  if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+  auto kern = odconv_sample_kernel<T, CIN, NT>;
+  static size_t lds_set = 0;
+  if (lds > lds_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); lds_set = lds; }
+  dim3 grid(p.M / 128, p.B);
+  if (grid.y > 65535) return MV_ERR_UNSUPPORTED;
+  if (slots_out) { *slots_out = 1; return MV_OK; }
+#ifdef MV_OD_TIMING
+  static long long* dbg = nullptr;
+  static int calls = 0;
+  if (!dbg) { hipMalloc(&dbg, 8192 * 8 * 8); hipMemcpyToSymbol(HIP_SYMBOL(od_dbg), &dbg, sizeof(dbg)); }
+  hipMemsetAsync(dbg, 0xff, 8192 * 8 * 8, stream);
+#endif
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, (const T*)x, (const T*)wp, (const T*)bias, alpha, pooled_in,
+                     (const T*)att_w, (const T*)att_b, (T*)y, pooled_out, p);
+#ifdef MV_OD_TIMING
+  if (++calls == 20) {
+    hipStreamSynchronize(stream);
+    static long long hbuf[8192 * 8];
+    hipMemcpy(hbuf, dbg, sizeof(hbuf), hipMemcpyDeviceToHost);
+    const long nwg = (long)grid.x * grid.y;
+    double avg[8] = {0}; int cnt[8] = {0};
+    for (long w = 0; w < nwg; ++w) for (int i = 0; i < 8; ++i) { long long v = hbuf[w * 8 + i]; if (v >= 0) { avg[i] += (double)v; cnt[i]++; } }
+    fprintf(stderr, "[sample timing] grid %u x %u marks (start, issued, alpha, staged, loop, end):", grid.x, grid.y);
+    for (int i = 0; i < 8; ++i) if (cnt[i]) fprintf(stderr, " %.0f", avg[i] / cnt[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
   return MV_OK;
 }
 
@@ -1806,7 +2037,13 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
         // 256 input channels, ks = 2*stride (ups1): 64-row workgroups keep their 16 mixed fragments per wave resident and walk
         // the sample's 96-column tiles - the bank fragments are fetched from L2 and mixed once per (sample, row block) instead
         // of once per tile (37 -> 28.5 us; 144-column tiles without the x look-ahead measured 34 us)
-        if (mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256) {
+        static int smp = -1;
+        if (smp < 0) { const char* e = getenv("MV_OD_SAMPLE"); smp = e ? atoi(e) : 1; }
+        // the whole sample resident in LDS, the mixed fragments streamed (ups1 at B = 32: see odconv_sample_kernel)
+        if (smp && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256 && B * (p.M / 128) >= 128) {
+          if constexpr (sizeof(T) == 2) rc = od_sample_launch<T, 256, 17>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
+        }
+        if (rc == MV_ERR_UNSUPPORTED && mt1 && transposed && p.ntaps == 2 && K <= 4 && !film_proj && act <= ACT_LRELU && Cin == 256) {
           // (fp32: 16 resident fragment PAIRS per wave need 256 VGPRs = one wave per SIMD: 98 us vs 77 on the one-tile kernel - not used)
           if constexpr (sizeof(T) == 2) rc = od_mt_launch<T, 1, 6, 256>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
         }

@@ -373,6 +373,37 @@ def test_odconv_kloop_first_upsampler(H, dtype, B, T):
     assert O.rel_l2(pout.view(B, -1, 256).sum(dim=1).cpu(), y.float().sum(dim=2).cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T", [(16, 256), (19, 250), (3, 256)])
+def test_odconv_sample_resident_second_upsampler(H, dtype, B, T):
+    """Second upsampler's geometry (ODConvTranspose1d 256 -> 128, x8): from 16 samples up the sample-resident kernel runs
+    (odconv_sample_kernel: whole sample in LDS by LDS-DMA, mixed A fragments streamed, 8-byte stores), below that - and for
+    T = 250, whose 251 columns do not fill the kernel's 17 column tiles - the multi-tile kernel; both against the generic fp32 HIP
+    kernel, with the channel sums handed to the next layer checked against the stored output."""
+    from hifigan_modified import functional as Fn, ops
+    from hifigan_modified import _native as N
+    from hifigan_modified.fused import OdconvFused
+    torch.manual_seed(11)
+    m = H.ODConvTranspose1d(256, 128, 16, stride=8, padding=4).cuda()
+    with torch.no_grad():
+        m.bias.copy_(torch.randn_like(m.bias) * 0.5)
+    x32 = torch.randn(B, 256, T, device="cuda")
+    x = x32.to(dtype)
+    fz = OdconvFused(m)
+    with torch.no_grad():
+        ref = m(x32, act="lrelu").cpu()
+        pooled = x.float().sum(dim=2).contiguous()
+        pout = torch.full((B, fz.pool_floats(B, T, dtype, N.ACT_LRELU)), float("nan"), device="cuda")
+        y = ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x), Fn._cache, pooled_in=pooled, pooled_out=pout, act=N.ACT_LRELU))
+        y2 = ops.ntc_to_nct(fz.forward_cl(ops.nct_to_ntc(x), Fn._cache, pooled_in=pooled, pooled_out=pout, act=N.ACT_LRELU))
+    bound = {torch.float16: 1.5e-3, torch.bfloat16: 8e-3}[dtype]
+    assert y.shape == ref.shape == (B, 128, 8 * T) and torch.equal(y, y2)
+    e = O.rel_l2(y.float().cpu(), ref)
+    assert e < bound, f"second upsampler {dtype} B={B} T={T}: {e:.2e}"
+    assert bool(torch.isfinite(pout).all())
+    assert O.rel_l2(pout.view(B, -1, 128).sum(dim=1).cpu(), y.float().sum(dim=2).cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float16, 2e-2)])
 @pytest.mark.parametrize("Tm", [32, 344])
 def test_plain_hifigan_v3_vs_cpu_restatement(H, dtype, tol, Tm):
