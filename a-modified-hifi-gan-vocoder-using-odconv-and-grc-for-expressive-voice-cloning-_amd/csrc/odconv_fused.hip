@@ -370,6 +370,66 @@ __device__ __forceinline__ void od_alpha_from_partials(float* alds, float* scrat
   }
 }
 
+// The same attention for ONE sample on ONE wave, no LDS and no barrier (K <= 4, Cin <= 512): lane l owns the channels l, l + 64, ..;
+// all of its loads - attention weights, bias, the producer's partial sums - are requested together and are the wave's first memory
+// traffic, so they are one round trip AHEAD of whatever the other waves of the workgroup stage meanwhile (the workgroup-wide form
+// above is two round trips and three barriers, and behind bulk loads its small requests wait for them: 9-12 k ticks in the
+// upsamplers' prologues).  The caller picks the wave and separates the write of alds from its readers with a barrier.
+template <typename T>
+__device__ __forceinline__ void od_alpha_wave(float* alds_s, int b, const OdP& p, const float* __restrict__ pooled_in,
+                                              const T* __restrict__ att_w, const T* __restrict__ att_b) {
+  const int lane = threadIdx.x & 63;
+  const int Cin = p.Cin, npc = p.pool_n / Cin;
+  uint32_t wq[4][OD_LU], bq[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int kb = k < p.K ? k : 0;
+#pragma unroll
+    for (int u = 0; u < OD_LU; ++u) {
+      const int cc = 64 * u + lane;
+      wq[k][u] = ldraw<T>(att_w + (long)kb * Cin + (cc < Cin ? cc : Cin - 1));
+    }
+    bq[k] = ldraw<T>(att_b ? att_b + kb : att_w);
+  }
+  float a[OD_LU];
+#pragma unroll
+  for (int u = 0; u < OD_LU; ++u) a[u] = 0.f;
+  const float* src = pooled_in + (long)b * p.pool_n;
+  int off[OD_LU];
+#pragma unroll
+  for (int u = 0; u < OD_LU; ++u) off[u] = 64 * u + lane < Cin ? 64 * u + lane : Cin - 1;
+  int j = 0;
+  for (; j + 1 < npc; j += 2) {                           // two partials of every owned channel in flight, added in index order
+    float v0[OD_LU], v1[OD_LU];
+#pragma unroll
+    for (int u = 0; u < OD_LU; ++u) { v0[u] = src[(long)j * Cin + off[u]]; v1[u] = src[(long)(j + 1) * Cin + off[u]]; }
+#pragma unroll
+    for (int u = 0; u < OD_LU; ++u) { a[u] += v0[u]; a[u] += v1[u]; }
+  }
+  if (j < npc) {
+#pragma unroll
+    for (int u = 0; u < OD_LU; ++u) a[u] += src[(long)j * Cin + off[u]];
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < OD_LU; ++u)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] += 64 * u + lane < Cin ? rawtofl<T>(wq[k][u]) * a[u] : 0.f;
+  wave_sum4_dpp(acc);
+  float z[4], mx = -INFINITY, den = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    z[k] = k < p.K ? acc[k] / (float)p.Tin + (att_b ? rawtofl<T>(bq[k]) : 0.f) : -INFINITY;
+    mx = fmaxf(mx, z[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { z[k] = k < p.K ? expf(z[k] - mx) : 0.f; den += z[k]; }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < p.K) alds_s[k] = z[k] / den;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 template <typename T, int S, int MW, int NB, bool PF, int KB>
 __global__ __launch_bounds__(256) void odconv_cl_kernel(const T* __restrict__ x, const T* __restrict__ wp,
@@ -991,29 +1051,41 @@ __global__ __launch_bounds__(512) void odconv_sample_kernel(const T* __restrict_
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) ring[slot][kb] = WL::load(wlane + (long)ks * 512 * ES + (kb < p.K ? kb : 0) * bank_stride);
   };
+  // ---- wave 7: alpha (odconv.py:36-40), its loads ahead of everything else it requests; waves 0-6: the sample's rows -> LDS
+  // (rows outside the sample fail the buffer range check and arrive as zeros)
+  const bool fastalpha = !alpha_in && p.K <= 4 && CIN <= 64 * OD_LU;
+  if (wid == 7 && fastalpha) {
+    od_alpha_wave<T>(alds, b, p, pooled_in, att_w, att_b);
 #pragma unroll
-  for (int i = 0; i < RD; ++i) ldring(i, i);
-  // ---- the sample's rows -> LDS (rows outside the sample fail the buffer range check and arrive as zeros)
-  {
+    for (int i = 0; i < RD; ++i) ldring(i, i);
+  } else {
     typedef __attribute__((address_space(3))) void lds_void;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(reinterpret_cast<const char*>(x)) + (long)b * p.Tin * RB, 0, p.Tin * RB, 0x00020000);
-    for (int i = wid; i < nrows; i += 8) {
+    const int nst = fastalpha ? 7 : 8;
+    for (int i = wid; i < nrows; i += nst) {
       const int tin = p.shift_lo + i;
       const unsigned gbase = (tin >= 0 && tin < p.Tin) ? (unsigned)(tin * RB) : 0x7ffffff0u;
       if (lane * 16 < RB) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(xl + i * RS), 16, gbase + lane * 16, 0, 0, 0);
     }
+    // the ring BEHIND the rows: the barrier below waits for everything but these RD * KB youngest loads
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < RD; ++i) ldring(i, i);
+    __builtin_amdgcn_sched_barrier(0);
   }
   OD_TM();
-  // ---- alpha (odconv.py:36-40)
-  if (alpha_in) {
-    if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
-  } else {
-    od_alpha_from_partials<T, 512>(alds, ascr, 1, b, p, pooled_in, att_w, att_b);
+  if (!fastalpha) {
+    if (alpha_in) {
+      if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+    } else {
+      od_alpha_from_partials<T, 512>(alds, ascr, 1, b, p, pooled_in, att_w, att_b);
+    }
   }
   OD_TM();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  static_assert(RD * KB == 16, "the counted wait below");
+  if (fastalpha) { asm volatile("s_waitcnt vmcnt(16)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }   // rows landed (and alds written); ring in flight
+  else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
   OD_TM();
   float al[KB];
 #pragma unroll
@@ -1203,15 +1275,23 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
 #else
   constexpr int kdbg = 0;
 #endif
-  if (XDMA && !(kdbg & 1)) {
+  // Attention on one wave per sample (the last S of the four waves; od_alpha_wave): no barrier, one round trip, requested ahead of the
+  // staging traffic that the other waves issue.
+  const int wu = __builtin_amdgcn_readfirstlane(wid);
+  const bool wavealpha = XDMA && !alpha_in && !kdbg && S <= 2 && p.K <= 4 && p.Cin <= 64 * OD_LU;
+  const int nstw = wavealpha ? 4 - S : 4;          // staging waves
+  if (wavealpha && wu >= nstw) {
+    const int s = wu - nstw;
+    if (b0 + s < p.B) od_alpha_wave<T>(alds + s * OD_MAXK, b0 + s, p, pooled_in, att_w, att_b);
+    else if (lane < OD_MAXK) alds[s * OD_MAXK + lane] = 0.f;
+  } else if (XDMA && !(kdbg & 1)) {
     typedef __attribute__((address_space(3))) void lds_void;
     const int RB = p.Cin * ES;                     // bytes of one row
-    const int wu = __builtin_amdgcn_readfirstlane(wid);
     const long xbytes = (long)p.B * p.Tin * RB;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(x)), 0,
                                                                          (int)(xbytes < 0x7fffffffL ? xbytes : 0x7fffffffL), 0x00020000);
     const int npc = (RB + 1023) >> 10;
-    for (int i = wu; i < S * p.nrows; i += 4) {
+    for (int i = wu; i < S * p.nrows; i += nstw) {
       const int s = i / p.nrows, r = i - s * p.nrows;
       const int tin = p.shift_lo + r;
       const bool ok = r < ZR && b0 + s < p.B && tin >= 0 && tin < p.Tin;
@@ -1222,7 +1302,9 @@ __global__ __launch_bounds__(256) void odconv_kloop_kernel(const T* __restrict__
     }
   }
   // ---- alpha (odconv.py:36-40)
-  if (alpha_in) {
+  if (wavealpha) {
+    OD_TM(); OD_TM(); OD_TM(); OD_TM();
+  } else if (alpha_in) {
     if (tid < S * p.K) {
       const int s = tid / p.K, kb = tid % p.K;
       alds[s * OD_MAXK + kb] = (b0 + s < p.B) ? alpha_in[(long)(b0 + s) * p.K + kb] : 0.f;
@@ -1765,14 +1847,23 @@ __global__ __launch_bounds__(OS_NW * 64) void odconv_stream_kernel(const void* _
   //  first, then the fragments, with the rows of the first tiles right behind them)
   constexpr bool early = false;
 
-  if (alpha_in) {
-    if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+  // (The one-wave chain of od_alpha_wave is a single round trip requested by wave 0 before anything else it asks for: the other seven
+  //  waves' fragment and row requests go out at once without getting in front of it.)
+  const bool wavealpha = !alpha_in && p.K <= 4 && CIN <= 64 * OD_LU;
+  if (wavealpha) {
+    if (__builtin_amdgcn_readfirstlane(wid) == 0) od_alpha_wave<float>(alds, b, p, pooled_in, att_w, att_b);
+    frag_loads(); first_rows();
+    lds_barrier();
   } else {
-    od_alpha_from_partials<float>(alds, reinterpret_cast<float*>(rings), 1, b, p, pooled_in, att_w, att_b);   // rings: nothing staged yet
+    if (alpha_in) {
+      if (tid < p.K) alds[tid] = alpha_in[(long)b * p.K + tid];
+    } else {
+      od_alpha_from_partials<float>(alds, reinterpret_cast<float*>(rings), 1, b, p, pooled_in, att_w, att_b);   // rings: nothing staged yet
+    }
+    __syncthreads();
   }
-  __syncthreads();
   OS_TM(0);
-  if (!early) { frag_loads(); first_rows(); }
+  if (!early && !wavealpha) { frag_loads(); first_rows(); }
   float al[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) al[kb] = kb < p.K ? alds[kb] : 0.f;
