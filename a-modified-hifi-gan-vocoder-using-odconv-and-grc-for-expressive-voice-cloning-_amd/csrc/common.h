@@ -164,7 +164,7 @@ int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const flo
 // internal cross-file entry (mrf_stream.hip): the MRF chain in its streaming form (MV_F32_W16, dilations (1, 3, 5) only)
 int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, int nblocks, char* ws, size_t act_bytes, int B, int Tn,
                          float eps, hipStream_t stream, const void** f_last, const void** x_last, int* x_last_pair,
-                         const float** part8_last, const float** tab_last, int* nwg_last);
+                         const float** part8_last, const float** tab_last, int* nwg_last, int x_pair_in = 0);
 
 // Zero fill as a KERNEL launch.  hipMemsetAsync becomes a memset node when a stream is being captured, and on this ROCm build a memset
 // node is not reliably ordered in front of the kernel node that follows it in a replayed graph: a captured training step whose

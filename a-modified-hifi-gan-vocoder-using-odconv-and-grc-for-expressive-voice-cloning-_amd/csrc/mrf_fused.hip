@@ -976,6 +976,8 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
                                        float eps, int dtype, void* stream) {
   MV_CHECK_ARG(x && wave && packed && dilations && workspace && conv_packed && nblocks >= 1 && nblocks <= 8 && B > 0 && B <= 65535 && T_ > 0);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)workspace & 255) == 0 && ks > 0 && (ks & 1));
+  const int x_pair_in = dtype == MV_F32_W16P;                          // x arrives as pair rows (streaming form only)
+  if (x_pair_in) dtype = MV_F32_W16;
   MrfMeta metas[8];
   for (int i = 0; i < nblocks; ++i) {
     MV_CHECK_ARG(packed[i] && ((uintptr_t)packed[i] & 15) == 0);
@@ -1001,9 +1003,10 @@ extern "C" int mv_mrf_chain_out_fwd_cl(const void* x, void* wave, const void* co
       break;
     case MV_F32_W16: {
       if (mrf_w16_stream() && fold && all_std) {     // streaming form (mrf_stream.hip)
-        rc = mvi_mrf_chain_stream(x, nullptr, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &x_pair, &p8, &tb8, &nwg8);
+        rc = mvi_mrf_chain_stream(x, nullptr, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &x_pair, &p8, &tb8, &nwg8, x_pair_in);
         if (rc != MV_ERR_UNSUPPORTED) break;
       }
+      if (x_pair_in) return MV_ERR_UNSUPPORTED;      // (the tile form reads fp32 rows)
       const int cfg = mrf_w16_nw() * 10 + mrf_w16_ntw();
 #define MV_W16_CHAIN(NW_, NTW_) mrf_chain_launch<f32w16, NW_, NTW_>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab, &fl, &xl_, fold ? &p8 : nullptr, &tb8, &nwg8)
       rc = cfg == 82 ? MV_W16_CHAIN(8, 2) : cfg == 81 ? MV_W16_CHAIN(8, 1) : cfg == 42 ? MV_W16_CHAIN(4, 2) : cfg == 161 ? MV_W16_CHAIN(16, 1) : MV_W16_CHAIN(4, 1);
@@ -1027,6 +1030,8 @@ extern "C" int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* 
                                    void* workspace, int B, int T_, float eps, int dtype, void* stream) {
   MV_CHECK_ARG(x && packed && dilations && workspace && nblocks >= 1 && nblocks <= 8 && B > 0 && B <= 65535 && T_ > 0);
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)workspace & 255) == 0);
+  const int x_pair_in = dtype == MV_F32_W16P;                          // x arrives as pair rows (streaming form only)
+  if (x_pair_in) dtype = MV_F32_W16;
   MrfMeta metas[8];
   for (int i = 0; i < nblocks; ++i) {
     MV_CHECK_ARG(packed[i] && ((uintptr_t)packed[i] & 15) == 0);
@@ -1063,9 +1068,10 @@ extern "C" int mv_mrf_chain_fwd_cl(const void* x, void* out, const void* const* 
       for (int i = 0; i < nblocks; ++i) all_std = all_std && mrf_meta_is_std(metas[i]);
       if (mrf_w16_stream() && all_std) {
         const void* fl = nullptr; const void* xl_ = nullptr; int xp = 0, nw = 0; const float* p8 = nullptr; const float* tb = nullptr;
-        rc = mvi_mrf_chain_stream(x, out, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &xp, &p8, &tb, &nw);
+        rc = mvi_mrf_chain_stream(x, out, packed, nblocks, ws, mrf_act_bytes(B, T_, 4), B, T_, eps, st, &fl, &xl_, &xp, &p8, &tb, &nw, x_pair_in);
         if (rc != MV_ERR_UNSUPPORTED) break;
       }
+      if (x_pair_in) return MV_ERR_UNSUPPORTED;
       const int cfg = mrf_w16_nw() * 10 + mrf_w16_ntw();
 #define MV_W16_CHAIN(NW_, NTW_) (out ? mrf_chain_launch<f32w16, NW_, NTW_>(x, out, packed, metas, nblocks, ws, B, T_, eps, st) \
                                      : mrf_chain_launch<f32w16, NW_, NTW_>(x, nullptr, packed, metas, nblocks, ws, B, T_, eps, st, ab_dummy, &fl_, &xl2_, &p8_, &tb_, &nw_))

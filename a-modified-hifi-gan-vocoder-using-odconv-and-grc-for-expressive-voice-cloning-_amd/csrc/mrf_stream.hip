@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   using VA = M::VA;
   using VB = M::VB;
   constexpr bool FULL = (MODE == SM_F0 || MODE == SM_F);
-  constexpr bool DMA = (MODE == SM_F);
+  constexpr bool DMA = (MODE == SM_F) || (MODE == SM_V0 && XPAIR);     // pair rows in HBM ARE the LDS operand image
   constexpr bool NEED5 = FULL, NEED8 = (MODE == SM_A);
   constexpr int WLB = FULL ? SR_WB_ALL : SR_WB_CONV;
 
@@ -318,18 +318,31 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
           for (int r = 0; r < 4; ++r) { const float q = ok ? v[m][r] : 0.f; s1[m] += q; s2[m] += q * q; }
       }
     };
-    if (nb > 0) {
-      fill_issue(0); fill_commit(0, 0);
-      fill_issue(1); fill_commit(1, 1);
+    if constexpr (!DMA) {
+      if (nb > 0) {
+        fill_issue(0); fill_commit(0, 0);
+        fill_issue(1); fill_commit(1, 1);
+      }
     }
     auto step = [&](auto uc, int j) {
       constexpr int U = decltype(uc)::value;
-      if (j + 2 < nb) fill_issue(j + 2);              // in flight under this tile's MFMAs
-      SR_TM(0);
-      tile(uc, j);
-      SR_TM(2);
-      if (j + 2 < nb) fill_commit(j + 2, (U + 2) % 3);
-      SR_TM(3);
+      if constexpr (DMA) {
+        // V0 on pair rows: batches 0-2 were requested in the prologue; tile j needs batches j and j + 1, and the only thing requested
+        // after them is DMA(j + 2) (5 instructions; nothing is stored in this pass).  Slot j % 3 is free behind the tile: batch j + 3.
+        if (j + 2 < nb) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SR_TM(0);
+        tile(uc, j);
+        SR_TM(2);
+        if (j + 3 < nb) dma(j + 3, U);
+        SR_TM(3);
+      } else {
+        if (j + 2 < nb) fill_issue(j + 2);              // in flight under this tile's MFMAs
+        SR_TM(0);
+        tile(uc, j);
+        SR_TM(2);
+        if (j + 2 < nb) fill_commit(j + 2, (U + 2) % 3);
+        SR_TM(3);
+      }
     };
     for (int j = 0; j < nt; j += 3) {
       step(std::integral_constant<int, 0>{}, j);
@@ -611,7 +624,7 @@ using namespace mv;
 // block's output are written; otherwise the caller gets (f_last, x_last, x_last_pair, part8, tab, nwg) for the fused output conv.
 int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, int nblocks, char* ws, size_t act_bytes, int B, int Tn,
                          float eps, hipStream_t stream, const void** f_last, const void** x_last, int* x_last_pair,
-                         const float** part8_last, const float** tab_last, int* nwg_last) {
+                         const float** part8_last, const float** tab_last, int* nwg_last, int x_pair_in) {
   if ((size_t)Tn * SR_ROWB >= (1ull << 31)) return MV_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   int L, nwg;
   sr_geometry(B, Tn, &L, &nwg);
@@ -628,15 +641,15 @@ int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, in
   a.Tn = Tn; a.L = L; a.nwg = nwg; a.eps = eps;
   { const char* e = getenv("MV_SR_DBG"); a.dbg = e ? atoi(e) : 0; }
   const void* xi = x;
-  bool xi_pair = false;
+  bool xi_pair = x_pair_in != 0;               // the producer already wrote pair rows (the last upsampler's streaming kernel)
   for (int i = 0; i < nblocks; ++i) {
     a.packed = (const char*)packed[i];
     if (i == 0) {
       a.x = xi; a.fprev = nullptr; a.out = nullptr; a.packed_prev = nullptr;
       a.part5_in = nullptr; a.part5_out = part5; a.part8_in = nullptr; a.part8_out = nullptr;
-      sr_launch<SM_V0, false>(a, B, stream);
+      if (xi_pair) sr_launch<SM_V0, true>(a, B, stream); else sr_launch<SM_V0, false>(a, B, stream);
       a.out = fbuf; a.part5_in = part5; a.part5_out = nullptr; a.part8_out = part8;
-      sr_launch<SM_F0, false>(a, B, stream);
+      if (xi_pair) sr_launch<SM_F, true>(a, B, stream); else sr_launch<SM_F0, false>(a, B, stream);
     } else {
       char* xn = xbuf[i & 1];
       a.x = xi; a.fprev = fbuf; a.out = xn; a.packed_prev = (const char*)packed[i - 1];

@@ -37,6 +37,7 @@ struct OdP {
   int film_F;
   int pool_n;     // floats per sample in pooled_in: slots * rows partial sums of the producing launch (Cin = dense sums)
   int in_f16;     // fp32 launch whose INPUT x is fp16 (mixed storage: the first fp32 stage reads the fp16 stream; multi-tile kernel only)
+  int out_pair;   // fp32 launch whose OUTPUT rows are written in the MRF chain's pair-row format (streaming kernel, 64 output channels)
 #ifdef MV_OD_TIMING
   int dbg;        // ablation switches of the timing build (MV_KL_DBG)
 #endif
@@ -1679,6 +1680,7 @@ static bool od_make(OdP* p, int B, int Cin, int Tin, int Cout, int Tout, int ks,
   p->nrows = 0;
   p->pool_n = Cin;
   p->in_f16 = 0;
+  p->out_pair = 0;
   return true;
 }
 
@@ -1910,7 +1912,7 @@ __global__ __launch_bounds__(OS_NW * 64) void odconv_stream_kernel(const void* _
   for (int m = 0; m < MT; ++m) {
     const int row = R0 + 16 * m + 4 * g, rr = row / p.Cout, o = row - rr * p.Cout;
     uofs[m] = rr - p.pad;
-    vo[m] = (uofs[m] * p.Cout + o) * 4;
+    vo[m] = p.out_pair ? uofs[m] * p.Cout * 4 + 32 * (o >> 3) + 8 * ((o >> 2) & 1) : (uofs[m] * p.Cout + o) * 4;
   }
   const float slope = p.act == ACT_NONE ? 1.f : p.slope;
   float psum[MT][4];
@@ -1969,7 +1971,17 @@ __global__ __launch_bounds__(OS_NW * 64) void odconv_stream_kernel(const void* _
         ov[i] = v >= 0.f ? v : v * slope;
         psum[m][i] += ok ? ov[i] : 0.f;
       }
-      if ((R0 + 16 * m) < p.M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), ry, qo + vo[m], 0, 0);
+      if ((R0 + 16 * m) < p.M) {
+        if (p.out_pair) {                                     // [8 x f16 hi | 8 x f16 lo] per 8-channel group: this lane's 4 channels = 8 + 8 bytes
+          uint32_t h0, l0, h1, l1;
+          Mma<f32w16>::split2(ov[0], ov[1], h0, l0);
+          Mma<f32w16>::split2(ov[2], ov[3], h1, l1);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, ry, qo + vo[m], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, ry, qo + vo[m] + 16, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), ry, qo + vo[m], 0, 0);
+        }
+      }
     }
   };
 
@@ -2094,6 +2106,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
     else if (K <= 4) rc = od_launch<T, S_, MW_, NB_, true, 4>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); \
     else rc = od_launch<T, S_, MW_, NB_, true, 8>(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, st_, slots_out); } while (0)
   if (p.in_f16 && (dtype != MV_F32 || ntiles <= 3 || wbytes > (1 << 20))) return MV_ERR_UNSUPPORTED;   // (only the multi-tile kernel below)
+  if (p.out_pair && (dtype != MV_F32 || ntiles <= 3 || wbytes > (1 << 20) || p.Cout != 64 || p.in_f16)) return MV_ERR_UNSUPPORTED;   // (only the 64-channel streaming kernel)
   MV_DISPATCH(dtype, {
     if (ntiles <= 3) {                       // short sequences, big kernels (input_proj, first upsampler)
       rc = MV_ERR_UNSUPPORTED;
@@ -2160,6 +2173,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
               else if (!p.in_f16 && Cin == 64) rc = od_stream_launch<64, 8, false>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
             }
             if (rc != MV_ERR_UNSUPPORTED) { /* launched (or sized) */ }
+            else if (p.out_pair) return rc;
             else if (p.in_f16) {
               if (Cin == 64) rc = od_mt_launch<T, 2, 4, 64, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
               else rc = od_mt_launch<T, 1, 4, 128, f16>(x, packed, bias, alpha, pooled_in, att_w, att_b, y, pooled_out, p, st_, slots_out);
@@ -2168,7 +2182,7 @@ static int od_dispatch(const void* x, const void* packed, const void* bias, cons
           }
         }
       }
-      if (p.in_f16) return rc;                               // only the multi-tile kernel widens its input
+      if (p.in_f16 || p.out_pair) return rc;                 // only the multi-tile / streaming kernels widen their input / write pair rows
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 2, 8);
       if (rc == MV_ERR_UNSUPPORTED) OD_GO(1, 1, 3);
     }
@@ -2181,7 +2195,7 @@ static int odconv_cl_fwd_impl(const void* x, const void* packed, const void* bia
                               const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
                               const void* film_proj, int film_F, void* y, float* pooled_out, int B, int Cin, int Tin,
                               int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
-                              float slope, int dtype, void* stream, int in_f16) {
+                              float slope, int dtype, void* stream, int in_f16, int out_pair = 0) {
   MV_CHECK_ARG(x && packed && y && (alpha || (pooled_in && att_w && pooled_in_count > 0 && pooled_in_count % Cin == 0)));
   MV_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)packed & 15) == 0);
   MV_CHECK_ARG(((uintptr_t)pooled_out & 15) == 0);
@@ -2190,6 +2204,7 @@ static int odconv_cl_fwd_impl(const void* x, const void* packed, const void* bia
     return MV_ERR_UNSUPPORTED;
   if (pooled_in) p.pool_n = pooled_in_count;
   p.in_f16 = in_f16;
+  p.out_pair = out_pair;
   const int rc = od_dispatch(x, packed, bias, alpha, pooled_in, att_w, att_b, film_proj, y, pooled_out, p, dtype,
                              (hipStream_t)stream, nullptr);
   if (rc != MV_OK) return rc;
@@ -2212,6 +2227,14 @@ extern "C" int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, cons
                                      int pad, int dil, int transposed, int K, int act, float slope, void* stream) {
   return odconv_cl_fwd_impl(x_f16, packed, bias, alpha, pooled_in, pooled_in_count, att_w, att_b, nullptr, 0, y, pooled_out, B, Cin,
                             Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, MV_F32, stream, 1);
+}
+
+extern "C" int mv_odconv_cl_fwd_pair(const void* x, const void* packed, const void* bias, const float* alpha,
+                                     const float* pooled_in, int pooled_in_count, const void* att_w, const void* att_b,
+                                     void* y_pair, float* pooled_out, int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride,
+                                     int pad, int dil, int transposed, int K, int act, float slope, void* stream) {
+  return odconv_cl_fwd_impl(x, packed, bias, alpha, pooled_in, pooled_in_count, att_w, att_b, nullptr, 0, y_pair, pooled_out, B, Cin,
+                            Tin, Cout, Tout, ks, stride, pad, dil, transposed, K, act, slope, MV_F32, stream, 0, 1);
 }
 
 extern "C" size_t mv_odconv_cl_pool_floats(int B, int Cin, int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil,

@@ -16,6 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "mi355x_vocoder
 
 MV_F32, MV_BF16, MV_F16 = 0, 1, 2
 MV_F32_W16 = 3        # mv_mrf_* operand mode: fp32 storage, hi + lo f16 activations x single f16 weights
+MV_F32_W16P = 4       # the same with the chain's INPUT already in pair rows (mv_odconv_cl_fwd_pair wrote it)
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_SILU = 0, 1, 2, 3
 
 _ERR = {-1: "MV_ERR_ARG (shape/size contract violated)", -2: "MV_ERR_DTYPE", -3: "MV_ERR_UNSUPPORTED"}

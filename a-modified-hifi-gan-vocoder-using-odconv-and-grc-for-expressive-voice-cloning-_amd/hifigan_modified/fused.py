@@ -5,6 +5,7 @@ boundary (mel in, waveform out - a [B,1,T] waveform is the same memory in both l
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_void_p
 
 import torch
@@ -113,7 +114,7 @@ class MrfChain:
             return N.MV_F32_W16, torch.float16
         return ops._dt(x_cl), x_cl.dtype
 
-    def forward_cl(self, x_cl, nblocks=None, w16=False, materialize=True):
+    def forward_cl(self, x_cl, nblocks=None, w16=False, materialize=True, x_pair=False):
         """x_cl [B, T, 64] contiguous -> output of block nblocks-1 (default: the last), a new tensor.  materialize=False: the
         chain's passes only (what the generator runs in front of its fused output conv) - returns None; bench.py times that."""
         n = len(self.mrfs) if nblocks is None else nblocks
@@ -132,12 +133,14 @@ class MrfChain:
         base = (ws.data_ptr() + 255) // 256 * 256
         out = torch.empty_like(x_cl) if materialize else None
         eps = float(self.mrfs[0].blk.norm.eps)
+        assert not x_pair or w16
         N.call("mv_mrf_chain_fwd_cl", c_void_p(x_cl.data_ptr()), None if out is None else c_void_p(out.data_ptr()), ptrs, dil, n,
-               c_void_p(base), B, T, eps, dt, ops._stream())
+               c_void_p(base), B, T, eps, N.MV_F32_W16P if x_pair else dt, ops._stream())
         return out
 
-    def forward_out_cl(self, x_cl, conv_packed, conv_bias, ks, act, w16=False):
-        """Chain + output projection + activation in one call (mv_mrf_chain_out_fwd_cl): x_cl [B, T, 64] -> wave [B, 1, T]."""
+    def forward_out_cl(self, x_cl, conv_packed, conv_bias, ks, act, w16=False, x_pair=False):
+        """Chain + output projection + activation in one call (mv_mrf_chain_out_fwd_cl): x_cl [B, T, 64] -> wave [B, 1, T].
+        x_pair: x_cl holds pair rows (OdconvFused.forward_cl(out_pair=True)); w16 only (MV_F32_W16P)."""
         n = len(self.mrfs)
         B, T, C = x_cl.shape
         assert C == 64 and x_cl.is_contiguous()
@@ -153,9 +156,10 @@ class MrfChain:
             self._ws[key] = ws                     # never evicted: a captured HIP graph may have baked this pointer in
         base = (ws.data_ptr() + 255) // 256 * 256
         wave = torch.empty(B, 1, T, device=x_cl.device, dtype=x_cl.dtype)
+        assert not x_pair or w16
         N.call("mv_mrf_chain_out_fwd_cl", c_void_p(x_cl.data_ptr()), c_void_p(wave.data_ptr()), ptrs, dil, n, c_void_p(base),
-               c_void_p(conv_packed.data_ptr()), float(conv_bias), int(ks), int(act), B, T, float(self.mrfs[0].blk.norm.eps), dt,
-               ops._stream())
+               c_void_p(conv_packed.data_ptr()), float(conv_bias), int(ks), int(act), B, T, float(self.mrfs[0].blk.norm.eps),
+               N.MV_F32_W16P if x_pair else dt, ops._stream())
         return wave
 
 
@@ -295,10 +299,12 @@ class OdconvFused:
         return n
 
     def forward_cl(self, x_cl, cache, alpha=None, pooled_in=None, film_proj=None, film_F=0, pooled_out=None,
-                   act=N.ACT_NONE, slope=0.1, storage=None):
+                   act=N.ACT_NONE, slope=0.1, storage=None, out_pair=False):
         """pooled_in / pooled_out: fp32 [B, n] partial channel sums (n = the producer's / this layer's pool_floats).
         storage = torch.float32 with an fp16 x_cl: the first fp32 stage of the mixed mode - the kernel widens its input while
-        staging it (mv_odconv_cl_fwd_in16) where that variant exists, else x_cl is cast first."""
+        staging it (mv_odconv_cl_fwd_in16) where that variant exists, else x_cl is cast first.
+        out_pair=True: returns (y, is_pair) - where the geometry has the variant (mv_odconv_cl_fwd_pair: fp32 storage, 64 output
+        channels, streaming kernel) y holds the MRF chain's pair rows instead of fp32 values (same shape and byte size)."""
         m = self.mod
         cin, cout, ks, stride, pad, dil, tr, K = self.geometry()
         B, Tin, C = x_cl.shape
@@ -307,7 +313,7 @@ class OdconvFused:
         att = m.kernel_attention[1]
         P = lambda t: None if t is None else c_void_p(t.data_ptr())
         if storage is not None and storage != x_cl.dtype:
-            if storage == torch.float32 and x_cl.dtype == torch.float16 and film_proj is None:
+            if storage == torch.float32 and x_cl.dtype == torch.float16 and film_proj is None and not out_pair:
                 y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=storage)
                 rc = N.lib().mv_odconv_cl_fwd_in16(P(x_cl), P(self.packed(storage, x_cl.device)), P(cache.get(m.bias, storage)), P(alpha),
                                                    P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
@@ -319,12 +325,26 @@ class OdconvFused:
                     return y
             x_cl = ops.cast(x_cl, storage)
         y = torch.empty(B, Tout, cout, device=x_cl.device, dtype=x_cl.dtype)
+        if out_pair:
+            if x_cl.dtype == torch.float32 and film_proj is None:
+                rc = N.lib().mv_odconv_cl_fwd_pair(P(x_cl), P(self.packed(x_cl.dtype, x_cl.device)), P(cache.get(m.bias, x_cl.dtype)), P(alpha),
+                                                   P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
+                                                   P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)), P(y), P(pooled_out),
+                                                   B, cin, Tin, cout, Tout, ks, stride, pad, dil, int(tr), K, int(act), float(slope),
+                                                   ops._stream())
+                if rc != -3:                                   # MV_ERR_UNSUPPORTED: no pair-row variant for this geometry
+                    N.check(rc, "mv_odconv_cl_fwd_pair")
+                    return y, True
+            return self.forward_cl(x_cl, cache, alpha, pooled_in, film_proj, film_F, pooled_out, act, slope), False
         N.call("mv_odconv_cl_fwd", P(x_cl), P(self.packed(x_cl.dtype, x_cl.device)), P(cache.get(m.bias, x_cl.dtype)),
                P(alpha), P(pooled_in), 0 if pooled_in is None else pooled_in.shape[1],
                P(cache.get(att.weight, x_cl.dtype)), P(cache.get(att.bias, x_cl.dtype)),
                P(film_proj), int(film_F), P(y), P(pooled_out), B, cin, Tin, cout, Tout, ks, stride, pad, dil, int(tr), K,
                int(act), float(slope), ops._dt(x_cl), ops._stream())
         return y
+
+
+_GEN_PAIR = os.environ.get("MV_GEN_PAIR", "0") == "1"
 
 
 class GeneratorFused:
@@ -421,9 +441,21 @@ class GeneratorFused:
         x = self.inp.forward_cl(x, cache, alpha=alpha0, film_proj=film_proj, film_F=F, pooled_out=views[0])
         if return_stages:
             st["film" if cond is not None else "input_proj"] = x
+        # two-product chain (streaming form): the last upsampler CAN write the chain's pair rows directly, so that the chain's first
+        # pass takes its input by LDS-DMA like every later one.  Off by default (MV_GEN_PAIR=1 turns it on): measured at C2, that first
+        # pass is bound by its stage-1 matrix work, not by its input path (21.8 us either way), while the upsampler's two 8-byte stores
+        # per lane instead of one 16-byte store cost it 4 us (33 -> 37 us).
+        w16 = bool(getattr(g, "_mv_mrf_w16", False)) and mixed is not None
+        want_pair = (_GEN_PAIR and w16 and not return_stages and self.chain is not None and dt == torch.float32 and len(self.ups) >= 2
+                     and sdt(len(self.ups)) == torch.float32 and sdt(len(self.ups) - 1) == torch.float32)
+        x_pair = False
         for i, u in enumerate(self.ups):
             nxt = views[i + 1] if i + 1 < len(self.ups) else None
             # (mixed mode: the first fp32-storage upsampler takes the fp16 stream as it is - the one storage-type change)
+            if want_pair and i == len(self.ups) - 1:
+                x, x_pair = u.forward_cl(x, cache, pooled_in=views[i], pooled_out=nxt, act=N.ACT_LRELU,
+                                         slope=g.upsample_layers[i][1].negative_slope, storage=sdt(i + 1), out_pair=True)
+                continue
             x = u.forward_cl(x, cache, pooled_in=views[i], pooled_out=nxt, act=N.ACT_LRELU,
                              slope=g.upsample_layers[i][1].negative_slope, storage=sdt(i + 1))
             if return_stages:
@@ -435,10 +467,9 @@ class GeneratorFused:
         # at C2.  16-bit storage keeps the per-block kernels (the chain's extra stream transfer costs more than the MFMAs it saves:
         # 174 vs 166 us).  The per-stage outputs, when asked for, are chains over the first i+1 blocks.
         use_chain = self.chain is not None and x.dtype == torch.float32
-        w16 = bool(getattr(g, "_mv_mrf_w16", False)) and mixed is not None
         if use_chain and not return_stages:
             wt, bias = self.out_weights(mel.device)
-            return self.chain.forward_out_cl(x, wt, bias, g.output_proj.kernel_size[0], N.ACT_TANH, w16=w16)
+            return self.chain.forward_out_cl(x, wt, bias, g.output_proj.kernel_size[0], N.ACT_TANH, w16=w16, x_pair=x_pair)
         if use_chain:
             x_in = x
             if return_stages:

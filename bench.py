@@ -367,7 +367,14 @@ def main():
             x_cl = ops.nct_to_ntc(st_["up%d" % (len(g.upsample_layers) - 1)])
             nblk, chained = 1, False
             if fzz is not None and fzz.chain is not None and x_cl.dtype == torch.float32:
-                run, nblk, chained = (lambda: fzz.chain.forward_cl(x_cl, w16=w16, materialize=False)), len(fzz.mrfs), True
+                x_in, pair = x_cl, False
+                from hifigan_modified import fused as _fz
+                if w16 and _fz._GEN_PAIR:     # (MV_GEN_PAIR=1: the generator hands the chain the last upsampler's pair rows - time that form)
+                    from hifigan_modified import functional as _F2
+                    li = len(g.upsample_layers) - 1
+                    xin = ops.nct_to_ntc(st_["up%d" % (li - 1)]).float().contiguous()
+                    x_in, pair = fzz.ups[li].forward_cl(xin, _F2._cache, pooled_in=xin.sum(dim=1).contiguous(), act=1, out_pair=True)
+                run, nblk, chained = (lambda: fzz.chain.forward_cl(x_in, w16=w16, materialize=False, x_pair=pair)), len(fzz.mrfs), True
             elif fzz is not None:
                 run = lambda: fzz.mrfs[0].forward_cl(x_cl)
             else:

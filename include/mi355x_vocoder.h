@@ -31,7 +31,12 @@ typedef enum { MV_F32 = 0, MV_BF16 = 1, MV_F16 = 2,
                /* operand mode of the mv_mrf_* entry points only: fp32 storage, every MFMA activation operand a hi + lo f16 pair, the
                 * weights a single f16 (pack with this code as well: the image is the MV_F16 one) - two products per MAC instead of
                 * MV_F32's three (hi + lo bf16 on both sides).  Not a storage type: every other entry point rejects it. */
-               MV_F32_W16 = 3 } mv_dtype;
+               MV_F32_W16 = 3,
+               /* mv_mrf_chain_fwd_cl / mv_mrf_chain_out_fwd_cl only: MV_F32_W16 whose INPUT x already is in the chain's internal row
+                * format ("pair rows": per time step and 8-channel group 8 f16 hi values followed by 8 f16 lo values, hi + lo = the fp32
+                * value to 22 bits; 256 bytes per 64-channel row, the size of the fp32 row).  mv_odconv_cl_fwd_pair writes that
+                * format.  Streaming form only (dilations (1, 3, 5)), MV_ERR_UNSUPPORTED otherwise. */
+               MV_F32_W16P = 4 } mv_dtype;
 typedef enum { MV_ACT_NONE = 0, MV_ACT_LRELU = 1, MV_ACT_TANH = 2, MV_ACT_SILU = 3 } mv_act;
 
 #define MV_OK 0
@@ -223,6 +228,14 @@ int mv_odconv_cl_fwd(const void* x, const void* packed, const void* bias, const 
  * MV_ERR_UNSUPPORTED otherwise - cast and call mv_odconv_cl_fwd. */
 int mv_odconv_cl_fwd_in16(const void* x_f16, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
                           int pooled_in_count, const void* att_w, const void* att_b, void* y, float* pooled_out, int B, int Cin,
+                          int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
+                          float slope, void* stream);
+/* mv_odconv_cl_fwd (dtype MV_F32, no FiLM) whose output rows are written in the MRF chain's pair-row format (see MV_F32_W16P): the
+ * last upsampler hands its result to mv_mrf_chain_out_fwd_cl without an fp32 round trip through registers - the chain's first pass
+ * reads pair rows by LDS-DMA.  Only the 64 -> 64 channel streaming kernel (ODConvTranspose1d, ks = 2 * stride); MV_ERR_UNSUPPORTED
+ * otherwise - call mv_odconv_cl_fwd and pass MV_F32_W16 to the chain.  pooled_out as in mv_odconv_cl_fwd. */
+int mv_odconv_cl_fwd_pair(const void* x, const void* packed, const void* bias, const float* alpha, const float* pooled_in,
+                          int pooled_in_count, const void* att_w, const void* att_b, void* y_pair, float* pooled_out, int B, int Cin,
                           int Tin, int Cout, int Tout, int ks, int stride, int pad, int dil, int transposed, int K, int act,
                           float slope, void* stream);
 /* floats PER SAMPLE that the launch above writes to pooled_out (0 = unsupported geometry): slots x GEMM rows, where the slot

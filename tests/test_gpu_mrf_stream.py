@@ -105,3 +105,61 @@ def test_graph_replay_survives_eager_call_at_another_shape(H):
         del junk
         torch.cuda.synchronize()
         assert torch.equal(gv.replay(), want)
+
+
+def _pair_rows(x_cl):
+    """fp32 [B, T, 64] -> the chain's pair rows (per 8-channel group: 8 f16 hi, 8 f16 lo), as an fp32-typed tensor of the same shape."""
+    B, T, C = x_cl.shape
+    g = x_cl.view(B, T, C // 8, 8)
+    hi = g.to(torch.float16)
+    lo = (g - hi.float()).to(torch.float16)
+    return torch.stack([hi, lo], dim=3).contiguous().view(torch.float32).view(B, T, C)
+
+
+def _unpair(y):
+    B, T, C = y.shape
+    h = y.contiguous().view(torch.float16).view(B, T, C // 8, 2, 8).float()
+    return (h[:, :, :, 0] + h[:, :, :, 1]).reshape(B, T, C)
+
+
+@pytest.mark.parametrize("B,T", [(2, 48), (3, 700), (1, 17), (2, 4100)])
+def test_stream_chain_takes_pair_rows(H, B, T):
+    """MV_F32_W16P: the chain fed with its own row format (what the last upsampler's streaming kernel writes) - the first pass reads it
+    by LDS-DMA - equals the chain fed with fp32 rows up to the 22-bit representation of the input (2^-22 relative)."""
+    from hifigan_modified.fused import MrfChain, mrf_fused_for
+    blks, _ = _blocks(H)
+    chain = MrfChain([mrf_fused_for(bk) for bk in blks])
+    torch.manual_seed(T + 1)
+    xc = torch.randn(B, T, 64, device="cuda")
+    with torch.no_grad():
+        for n in (1, 3):
+            a = chain.forward_cl(xc, n, w16=True)
+            b = chain.forward_cl(_pair_rows(xc), n, w16=True, x_pair=True)
+            b2 = chain.forward_cl(_pair_rows(xc), n, w16=True, x_pair=True)
+            assert torch.equal(b, b2)
+            assert O.rel_l2(b.cpu(), a.cpu()) < 2e-6, (n, O.rel_l2(b.cpu(), a.cpu()))
+
+
+@pytest.mark.parametrize("B,T", [(2, 64), (3, 1000), (32, 4096)])
+def test_last_upsampler_writes_pair_rows(H, B, T):
+    """mv_odconv_cl_fwd_pair: the 64 -> 64 channel ODConvTranspose1d (x2) of the generator writes the chain's pair rows; decoded
+    (hi + lo) they are the fp32 output of the same kernel to 2^-22, and the channel sums handed on are the same numbers."""
+    from hifigan_modified import functional as Fn, ops
+    from hifigan_modified import _native as N
+    from hifigan_modified.fused import OdconvFused
+    torch.manual_seed(5)
+    m = H.ODConvTranspose1d(64, 64, 4, stride=2, padding=1).cuda()
+    with torch.no_grad():
+        m.bias.copy_(torch.randn_like(m.bias) * 0.5)
+    fz = OdconvFused(m)
+    x = torch.randn(B, T, 64, device="cuda")
+    pooled = x.sum(dim=1).contiguous()
+    n = fz.pool_floats(B, T, torch.float32, N.ACT_LRELU)
+    with torch.no_grad():
+        p1 = torch.full((B, n), float("nan"), device="cuda")
+        p2 = torch.full((B, n), float("nan"), device="cuda")
+        y = fz.forward_cl(x, Fn._cache, pooled_in=pooled, pooled_out=p1, act=N.ACT_LRELU)
+        yp, is_pair = fz.forward_cl(x, Fn._cache, pooled_in=pooled, pooled_out=p2, act=N.ACT_LRELU, out_pair=True)
+    assert is_pair and yp.shape == y.shape
+    assert float((_unpair(yp) - y).abs().max()) <= 2.0 ** -21 * float(y.abs().max())
+    assert torch.equal(p1, p2)
