@@ -266,6 +266,17 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   //      Software-pipelined (the operands of k-step s + 1 are read while the MFMAs of k-step s run); `between(s)` is called once per
   //      k-step, behind its MFMAs: pass F hangs one slice of the PREVIOUS tile's stages 2-3 there, so the VALU work of one tile
   //      (GroupNorm + SiLU, operand split, statistics: ~200 instructions) issues in the shadow of the next tile's 64 stage-1 MFMAs
+  // Pass V0 keeps the 32 stage-1 weight fragments in REGISTERS (it has the room: 120 VGPRs without them).  Read from LDS per k-step
+  // they are 32 KB per 16-step tile and wave against 28 KB of activation operands - with eight waves per CU the LDS array, not the
+  // matrix pipe, set the pace of this pass (21.8 us for 6.8 us of MFMA time, whether its rows came through registers or by LDS-DMA).
+  constexpr bool AREG = (MODE == SM_V0);
+  VA areg[AREG ? 16 : 1][2];
+  if constexpr (AREG) {
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) areg[f][ks] = M::load_a(wl + (size_t)(f * 2 + ks) * FRAG_BYTES + lane * 16, 0);
+  }
   auto stage1 = [&](auto uc, f32x4 (&v)[4], VB (&xb0)[2], auto&& between) {
     constexpr int U = decltype(uc)::value;
 #pragma unroll
@@ -277,7 +288,10 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
       bfr[set] = M::load_bp(lds + baddr[tap][U] + ks * 128, 16);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
-        if (mrf_std_frag(m, tap) >= 0) afr[set][m] = M::load_a(wl + (size_t)(mrf_std_frag(m, tap) * 2 + ks) * FRAG_BYTES + lane * 16, 0);
+        if (mrf_std_frag(m, tap) >= 0) {
+          if constexpr (AREG) afr[set][m] = areg[mrf_std_frag(m, tap)][ks];
+          else afr[set][m] = M::load_a(wl + (size_t)(mrf_std_frag(m, tap) * 2 + ks) * FRAG_BYTES + lane * 16, 0);
+        }
     };
     ld_step(0, 0);
 #pragma unroll
