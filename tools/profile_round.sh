@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # Raw output goes to gpurun_out/<tag>_prof/ (scratch); tools/profile_summary.py turns it into profiles/ on either side.
 # Counter passes are separate runs with --kernel-trace only (never mixed with other trace domains).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOTD=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOTD/gpurun_out/${TAG}_prof
 mkdir -p $OUT
@@ -15,7 +15,8 @@ run() { d=$OUT/$1; shift; mkdir -p $d; "$@" > $d/log.txt 2>&1 || { tail -n 5 $d/
 run bench_trace rocprofv3 --kernel-trace --output-format csv -d $OUT/bench_trace -- python3 $ROOTD/bench.py --steps 100
 grep '^{"metric"' $OUT/bench_trace/log.txt > $OUT/bench_line_profiled.json || true
 # 2. HBM traffic, inference, per storage type: FETCH_SIZE and WRITE_SIZE in separate passes
-for dt in fp32 bf16; do
+# (mixed = the headline mode: fp16 storage through up1, fp32 storage behind it, MRF chain with two-product operands - summary tag fp32w16)
+for dt in mixed bf16; do
   run fetch_$dt rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch_$dt -- python3 $ROOTD/bench.py --dtype $dt $INF
   run write_$dt rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write_$dt -- python3 $ROOTD/bench.py --dtype $dt $INF
 done
@@ -26,9 +27,8 @@ run write_train rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d
 # 4. summaries (small; the raw csv files stay in gpurun_out/)
 cd $ROOTD
 python3 tools/profile_summary.py stats $OUT/bench_trace profiles/${TAG}_bench_kernel_stats.csv
-for dt in fp32 bf16; do
-  python3 tools/profile_summary.py traffic $OUT/fetch_$dt $OUT/write_$dt profiles/${TAG}_${dt}_pmc_traffic.json --dtype $dt --workload "bench.py --dtype $dt $INF"
-done
+python3 tools/profile_summary.py traffic $OUT/fetch_mixed $OUT/write_mixed profiles/${TAG}_mixed_pmc_traffic.json --dtype fp32w16 --workload "bench.py --dtype mixed $INF"
+python3 tools/profile_summary.py traffic $OUT/fetch_bf16 $OUT/write_bf16 profiles/${TAG}_bf16_pmc_traffic.json --dtype bf16 --workload "bench.py --dtype bf16 $INF"
 python3 tools/profile_summary.py traffic $OUT/fetch_train $OUT/write_train profiles/${TAG}_train_bf16_pmc_traffic.json --dtype train_bf16 --workload "bench.py $TR"
 cp $OUT/bench_line_profiled.json profiles/${TAG}_bench_line_profiled.json 2>/dev/null || true
 mkdir -p gpurun_out/${TAG}_profiles && cp profiles/${TAG}_* gpurun_out/${TAG}_profiles/

@@ -83,7 +83,7 @@ def traffic(args):
         json.dump(out, fh, indent=1)
     print(f"{args.out}: {len(kernels)} kernels")
     for k, v in kernels.items():
-        if "mrf_kernel" in k or "odconv" in k or "conv_out" in k:
+        if "mrf_kernel" in k or "mrf_stream" in k or "odconv" in k or "conv_out" in k:
             print(f"  {k[:100]:100s} R {v['fetch_bytes_per_launch'] / 1e6:8.2f} MB  W {v['write_bytes_per_launch'] / 1e6:8.2f} MB  x{v['launches']}")
 
 
