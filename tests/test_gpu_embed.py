@@ -274,3 +274,31 @@ def test_extractor_with_16bit_parameters_matches_fp32_masters(H):
     mh = copy.deepcopy(m).half()
     spk_h, emo_h = mh(x)
     assert rel_l2(spk_h.float().cpu(), spk.float().cpu()) < 3e-3 and rel_l2(emo_h.float().cpu(), emo.float().cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_two_stream_extractor_equals_one_stream_eager_and_captured(H, dtype):
+    """EmbeddingExtractor runs its two encoders as parallel stream branches (embedding_extractors.py): the embeddings are the bits of
+    the one-stream forward, issued eagerly and replayed from a captured graph (GraphedExtractor), and repeat bit for bit."""
+    from hifigan_modified import embedding_extractors as E
+    from hifigan_modified.graphs import GraphedExtractor
+    torch.manual_seed(3)
+    ex = H.EmbeddingExtractor().cuda().train(False)
+    mel = torch.randn(5, 80, 48, device="cuda").to(dtype)
+    if dtype != torch.float32:
+        ex = ex.to(dtype)
+    saved = E._TWO_STREAMS
+    try:
+        E._TWO_STREAMS = False
+        s1, e1 = [t.clone() for t in ex(mel)]
+        E._TWO_STREAMS = True
+        s2, e2 = [t.clone() for t in ex(mel)]
+        s3, e3 = [t.clone() for t in ex(mel)]
+        g = GraphedExtractor(ex, mel)
+        sg, eg = [t.clone() for t in g(mel)]
+        sg2, eg2 = [t.clone() for t in g(mel)]
+    finally:
+        E._TWO_STREAMS = saved
+    torch.cuda.synchronize()
+    for a, b in ((s1, s2), (e1, e2), (s2, s3), (e2, e3), (s1, sg), (e1, eg), (sg, sg2), (eg, eg2)):
+        assert torch.equal(a, b)
