@@ -99,7 +99,29 @@ class FlatAdamW:
             pin[:raw.numel()].copy_(raw)
             cap["keep"].append(pin)
             return pin[:raw.numel()].to(self.flat_g.device, non_blocking=True)
-        return raw.to(self.flat_g.device, non_blocking=True)
+        # eager path: a ring of pinned staging buffers, so that the copy is a real asynchronous H2D (from pageable memory it is staged
+        # synchronously - a host stall per bucket while the backward is producing the next gradients).  A slot is reused only after the
+        # copy that last read it has completed (event per slot; in steady state it has, long ago).
+        ring = getattr(self, "_pin_ring", None)
+        if ring is None:
+            ring = self._pin_ring = {"slots": [], "next": 0}
+        n = raw.numel()
+        if len(ring["slots"]) < 16:
+            ring["slots"].append([torch.empty(max(n, 4096), dtype=torch.uint8).pin_memory(), None])
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["next"] % 16]
+            ring["next"] += 1
+            if slot[1] is not None:
+                slot[1].synchronize()
+            if slot[0].numel() < n:
+                slot[0] = torch.empty(n, dtype=torch.uint8).pin_memory()
+        slot[0][:n].copy_(raw)
+        dev = slot[0][:n].to(self.flat_g.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.flat_g.device))
+        slot[1] = ev
+        return dev
 
     def gather_range(self, i0, i1):
         """Gather the gradients of parameters i0..i1-1 only (one launch): the per-bucket form used by
