@@ -147,3 +147,49 @@ def test_overlapped_bucket_allreduce_gloo_world2():
     assert all(v == 0.0 for v in f0[n:])                          # the frozen parameter
     # the six trainable parameters were reduced from hooks, output layer first; only the frozen one waited for finish()
     assert inb0 == inb1 == [5, 4, 3, 2, 1, 0] and ord0[-1] == 6
+
+
+def _order_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from conftest import PKG, ROOT  # noqa: F401
+    from hifigan_modified.parallel import OverlappedGradSync, init_distributed
+    init_distributed("gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (40, 24, 8, 56, 16, 32)]
+    arena = _CpuArena(params)
+    sync = OverlappedGradSync(arena, bucket_mib=0)          # one bucket per parameter
+    order = []
+    orig = sync._launch
+    sync._launch = lambda b: (order.append(b), orig(b))[1]
+    torch.manual_seed(20 + rank)
+    grads = [torch.randn_like(p) for p in params]
+    # the gradients become ready in a DIFFERENT order on each rank (rank 0: first parameter first; rank 1: a shuffle)
+    ready = list(range(len(params))) if rank == 0 else [3, 5, 0, 4, 1, 2]
+    sync.begin()
+    for i in ready:
+        params[i].grad = grads[i]
+        sync._make_hook(i)(params[i])
+    scale = sync.finish()
+    flat = torch.cat([arena.flat_g[o:o + p.numel()] for p, o in zip(arena.params, arena.offsets)]) * scale
+    q.put((rank, order, flat.tolist(), torch.cat(grads).tolist()))
+    dist.destroy_process_group()
+
+
+def test_bucket_collectives_are_issued_in_one_order_on_every_rank():
+    """Gradients that become ready in different orders on the two ranks still produce the same sequence of bucket all-reduces
+    (descending bucket index - the order RCCL needs on one communicator), and the reduced buffer is the mean of the ranks' gradients."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, o0, f0, g0), (_, o1, f1, g1) = res
+    assert o0 == o1 == [5, 4, 3, 2, 1, 0]
+    assert f0 == f1
+    assert max(abs(a - (b + c) / 2) for a, b, c in zip(f0, g0, g1)) < 1e-6
