@@ -413,19 +413,30 @@ def main():
             od_roof = []
             from hifigan_modified import functional as _Fn
             elt = mel.element_size()
+            names = {0: "odconv_kloop_kernel (banks as stored, weights-stationary over 2 samples)", 1: "odconv_sample_kernel (sample resident in LDS)",
+                     2: "odconv_stream_kernel<128,4,fp16 in>", 3: "odconv_stream_kernel<64,8>"} if args.dtype == "mixed" else {}
             with torch.no_grad():
-                for li in (len(fz.ups) - 2, len(fz.ups) - 1):
+                for li in range(len(fz.ups)):
                     u = fz.ups[li]
-                    xin = ops.cast(ops.nct_to_ntc(st["up%d" % (li - 1)] if li > 0 else st["film"]), mel.dtype)   # (mixed: these layers run in fp32)
+                    # every layer exactly as the generator runs it: input in its producer's storage type, output in its own
+                    xin = ops.nct_to_ntc(st["up%d" % (li - 1)] if li > 0 else st["film"]).contiguous()
+                    sdt_ = st["up%d" % li].dtype
                     pooled = xin.float().sum(dim=1).contiguous()
-                    run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1)
+                    run = lambda: u.forward_cl(xin, _Fn._cache, pooled_in=pooled, act=1, storage=sdt_)
                     y = run()
                     ms_u = graph_time_ms(run)
-                    byts = (xin.numel() + y.numel()) * elt
-                    od_roof.append({"kernel": "mv::odconv_cl_*_kernel<%s> (upsample_layers.%d: %d->%d ch, x%d)" % (mrf_tag, li, u.mod.in_channels, u.mod.out_channels, u.mod.stride),
+                    wb = u.mod.kernels.numel() * (2 if sdt_ != torch.float32 else 4)           # the K banks, read once
+                    byts = xin.numel() * xin.element_size() + y.numel() * y.element_size() + wb
+                    od_roof.append({"kernel": "mv::%s (upsample_layers.%d: %d->%d ch, x%d, %s -> %s)" % (
+                                        names.get(li, "odconv_cl_*_kernel<%s>" % mrf_tag), li, u.mod.in_channels, u.mod.out_channels, u.mod.stride,
+                                        str(xin.dtype).replace("torch.", ""), str(sdt_).replace("torch.", "")),
                                     "bound": "hbm", "achieved": round(byts / (ms_u * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": round(byts / (ms_u * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes_per_launch": byts,
-                                    "ms_per_launch": round(ms_u, 4)})
+                                    "ms_per_launch": round(ms_u, 4),
+                                    "note": "algorithmic bytes = input + output once at their storage widths + the K kernel banks once (SURVEY 8(d)); "
+                                            "the first two upsamplers are bound by the bank stream out of L2 and the per-sample kernel mix, not by HBM "
+                                            "(DESIGN.md section 4)" if li < 2 else
+                                            "algorithmic bytes = input + output once at their storage widths + the K kernel banks once (SURVEY 8(d))"})
         del st
 
     # ---------------------------------------------------------------- the 16-bit storage modes beside the headline (rank 0, N=1)
