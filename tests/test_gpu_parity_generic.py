@@ -374,11 +374,12 @@ def test_odconv_kloop_first_upsampler(H, dtype, B, T):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("B,T", [(16, 256), (19, 250), (3, 256)])
+@pytest.mark.parametrize("B,T", [(16, 256), (19, 250), (3, 256), (17, 271), (16, 260), (16, 272)])
 def test_odconv_sample_resident_second_upsampler(H, dtype, B, T):
     """Second upsampler's geometry (ODConvTranspose1d 256 -> 128, x8): from 16 samples up the sample-resident kernel runs
-    (odconv_sample_kernel: whole sample in LDS by LDS-DMA, mixed A fragments streamed, 8-byte stores), below that - and for
-    T = 250, whose 251 columns do not fill the kernel's 17 column tiles - the multi-tile kernel; both against the generic fp32 HIP
+    (odconv_sample_kernel: whole sample in LDS by LDS-DMA, mixed A fragments streamed, 8-byte stores; 257..272 columns, i.e.
+    T = 256..271 - both ends tested), below that - and for T = 250 / 272, whose columns do not fit the kernel's 17 column tiles - the
+    multi-tile kernel; both against the generic fp32 HIP
     kernel, with the channel sums handed to the next layer checked against the stored output."""
     from hifigan_modified import functional as Fn, ops
     from hifigan_modified import _native as N
