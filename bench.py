@@ -603,12 +603,24 @@ def main():
 
         use_graph = world == 1 and not args.train_eager and not args.eager
         tdtype = getattr(torch, DT[args.train_dtype])
-        tel, lf, ovs, voc, trainer = train_leg(args.train_dtype, args.train_steps, args.train_warmup, use_graph)
+        graph_note = None
+        try:
+            tel, lf, ovs, voc, trainer = train_leg(args.train_dtype, args.train_steps, args.train_warmup, use_graph)
+        except Exception as exc:        # a capture that fails must not cost the metric: time the step as issued
+            if not use_graph:
+                raise
+            graph_note = "graph capture failed (%s: %s); timed eagerly" % (type(exc).__name__, str(exc)[:200])
+            print("bench.py: " + graph_note, file=sys.stderr)
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            use_graph = False
+            tel, lf, ovs, voc, trainer = train_leg(args.train_dtype, args.train_steps, args.train_warmup, False)
         coll = ("RCCL (torch.distributed 'nccl' backend over xGMI)" if backend == "nccl" else "torch.distributed '%s' backend (a rehearsal: NOT RCCL)" % backend)
         train = {"metric": "train audio-samples/s (G fwd + D step + G step + mel/STFT loss + AdamW)",
                  "value": round(B * Tm * 256 * world * args.train_steps / tel, 1), "unit": "samples/s",
                  "ms_per_step": round(tel / args.train_steps * 1e3, 2), "steps": args.train_steps, "dtype": args.train_dtype,
                  "launch": "hipgraph (the whole step - ~1000 launches - captured after 2 eager steps and replayed)" if use_graph else "eager",
+                 **({"launch_note": graph_note} if graph_note else {}),
                  "global_batch": B * world, "losses_finite": all(x == x and abs(x) != float("inf") for x in lf.values()),
                  "parallelism": ("dp%d, gradient buckets all-reduced under the backward over %s" % (world, coll)) if world > 1 else "single GPU"}
         if world > 1 and ovs:
