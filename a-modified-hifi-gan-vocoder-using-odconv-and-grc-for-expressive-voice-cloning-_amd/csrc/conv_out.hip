@@ -248,7 +248,9 @@ __global__ void conv_out_pack_all_kernel(const P* __restrict__ w, char* __restri
 //   z[tap][pos] = sum_c w[tap][c] * row[pos][c]   (A = the weights as a 16 x 64 operand, zero beyond ks; B = the staged rows, PRE-SPLIT
 //   into hi + lo bf16 planes when they are committed; 2 k-steps x 3 products per 16 positions, every row read ONCE),
 //   y[t] = bias + sum_tap z[tap][t + tap]          (the z tile replaces the rows in LDS after a barrier; 11 adds per output).
-template <int C, bool XPAIR>     // XPAIR: x arrives as pair rows (8 groups of [8 x f16 hi | 8 x f16 lo], mrf_stream.hip) instead of fp32 rows
+// XFMT: 0 = f and x fp32 rows; 1 = x as pair rows (8 groups of [8 x f16 hi | 8 x f16 lo], mrf_stream.hip), f fp32; 2 = f and x as hl8
+// rows (mfma.h: 192 bytes, f16 hi plane + e4m3 lo plane); 3 = f hl8, x fp32 (a one-block chain); 4 = x hl8, f fp32
+template <int C, int XFMT>
 __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* __restrict__ f, const float* __restrict__ x,
                                                                    const float* __restrict__ ab, const float* __restrict__ w, float bias,
                                                                    float* __restrict__ y, int Tn, int ks, int pad, int act,
@@ -303,15 +305,26 @@ __global__ __launch_bounds__(256) void conv_out_affine_mfma_kernel(const float* 
       const int r = r0 + u * (256 / CPR), t = t0 - pad + r;
       ok[u] = r < rows && t >= 0 && t < Tn;
       const size_t off = (size_t)(ok[u] ? t : 0) * C + ch * 4;
-      if constexpr (XPAIR) {
-        typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+      typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+      // this thread's 4 channels of an hl8 row: 8 bytes of the hi plane, 4 of the lo plane (the row index is per SAMPLE-relative t)
+      auto hl4 = [&](const float* base) {
+        const char* p = reinterpret_cast<const char*>(base) + ((size_t)b * Tn + (ok[u] ? t : 0)) * SR_HLB;
+        const f16x4_t h = *reinterpret_cast<const f16x4_t*>(p + ch * 8);
+        const int l = *reinterpret_cast<const int*>(p + 128 + ch * 4);
+        const f32x2_t l0 = __builtin_amdgcn_cvt_pk_f32_fp8(l, false), l1 = __builtin_amdgcn_cvt_pk_f32_fp8(l, true);
+        return f32x4{(float)h[0] + l0[0] * SR_LOI, (float)h[1] + l0[1] * SR_LOI, (float)h[2] + l1[0] * SR_LOI, (float)h[3] + l1[1] * SR_LOI};
+      };
+      if constexpr (XFMT == 2 || XFMT == 4) {
+        xv[u] = hl4(x);
+      } else if constexpr (XFMT == 1) {
         const char* px = reinterpret_cast<const char*>(xb) + (size_t)(ok[u] ? t : 0) * (C * 4) + (ch >> 1) * 32 + (ch & 1) * 8;
         const f16x4_t h = *reinterpret_cast<const f16x4_t*>(px), l = *reinterpret_cast<const f16x4_t*>(px + 16);
         xv[u] = f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
       } else {
         xv[u] = *reinterpret_cast<const f32x4*>(xb + off);
       }
-      fv[u] = *reinterpret_cast<const f32x4*>(fb + off);
+      if constexpr (XFMT == 2 || XFMT == 3) fv[u] = hl4(f);
+      else fv[u] = *reinterpret_cast<const f32x4*>(fb + off);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -381,11 +394,14 @@ int mvi_conv_out_affine(const void* f, const void* x, const float* ab, const flo
   if (dtype == MV_F32 && use_mfma && ks <= 16) {
     const size_t rows16 = (size_t)((256 + ks - 1 + 15) / 16) * 16;
     const size_t lds = rows16 * (2 * 64 * 2 + 16);       // >= the z tile (16 x 288 floats)
-    auto kern = x_pair ? conv_out_affine_mfma_kernel<64, true> : conv_out_affine_mfma_kernel<64, false>;
-    static size_t lds_set_m[2] = {0, 0};
-    if (lds > lds_set_m[x_pair ? 1 : 0]) {
+    if (x_pair < 0 || x_pair > 4) return MV_ERR_ARG;
+    auto kern = x_pair == 4 ? conv_out_affine_mfma_kernel<64, 4> : x_pair == 3 ? conv_out_affine_mfma_kernel<64, 3>
+              : x_pair == 2 ? conv_out_affine_mfma_kernel<64, 2> : x_pair == 1 ? conv_out_affine_mfma_kernel<64, 1>
+              : conv_out_affine_mfma_kernel<64, 0>;
+    static size_t lds_set_m[5] = {0, 0, 0, 0, 0};
+    if (lds > lds_set_m[x_pair]) {
       (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      lds_set_m[x_pair ? 1 : 0] = lds;
+      lds_set_m[x_pair] = lds;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const float*)f, (const float*)x, ab, wt, bias, (float*)y, T_, ks, pad, act,
                        part8, tab8, nwg, eps);

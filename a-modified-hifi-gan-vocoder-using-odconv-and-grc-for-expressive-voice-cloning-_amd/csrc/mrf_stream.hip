@@ -33,6 +33,10 @@ constexpr int SR_WB_ALL = (MRF_CONV_FRAGS + MRF_RES_FRAGS + MRF_FUS_FRAGS) * FRA
 constexpr int SR_WB_CONV = MRF_CONV_FRAGS * FRAG_BYTES;
 constexpr int SR_ROWB = 256;                // bytes of one row in HBM (fp32 [64] or pair)
 
+// f as hl8 rows as well: measured at C2 it costs more than it saves - the encode (cvt, residual, clamp, cvt: ~5 VALU per value) lands
+// in the matrix-bound F passes (+1.3 us each, F0 +3.1) while the A passes and the output conv, which read f, are not bound by bytes any
+// more once x' is 192 bytes (A 37 -> 33 us either way).  The code paths stay (final kernel, output conv, tests of the format).
+constexpr bool SR_FHL = false;
 enum { SM_V0 = 0, SM_F0 = 1, SM_A = 2, SM_F = 3 };
 // V0: fp32 rows -> statistics of v.   F0: fp32 rows -> f (fp32) + statistics of f.   F: pair rows (LDS-DMA) -> the same.
 // A : f_prev (fp32), x_prev (fp32 or pair rows) -> x' = a f + b + x as pair rows (written once) + statistics of v'.
@@ -58,13 +62,21 @@ __device__ long long* sr_dbg = nullptr;     // [mode][wave][8]: wait, stage 1, s
 #define SR_TM(slot) do {} while (0)
 #endif
 
-template <int MODE, bool XPAIR>
+// HL: the streams between the blocks (x' and f) are hl8 rows (mfma.h) instead of pair / fp32 rows.  Then F0 writes f as hl8, A reads
+// f as hl8 and x as fp32 rows (XPAIR false: block 1) or hl8 rows (XPAIR true) and writes x' as hl8, F reads x' through registers
+// (hi plane = the operand image's hi halves as they are, lo bytes widened to f16) and writes f as hl8.  V0 is not affected.
+template <int MODE, bool XPAIR, bool HL>
 __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   using M = Mma<f32w16>;
   using VA = M::VA;
   using VB = M::VB;
   constexpr bool FULL = (MODE == SM_F0 || MODE == SM_F);
-  constexpr bool DMA = (MODE == SM_F) || (MODE == SM_V0 && XPAIR);     // pair rows in HBM ARE the LDS operand image
+  constexpr bool DMA = ((MODE == SM_F) && !HL) || (MODE == SM_V0 && XPAIR);     // pair rows in HBM ARE the LDS operand image
+  constexpr bool XHL = HL && (MODE == SM_F || (MODE == SM_A && XPAIR));          // x arrives as hl8 rows
+  constexpr bool FHL = HL && SR_FHL;                                             // f as hl8 rows too (off: see SR_FHL)
+  constexpr int XRB = XHL ? SR_HLB : SR_ROWB;                                    // row bytes of x (in), of f (in or out), of x' (out)
+  constexpr int FRB = FHL ? SR_HLB : SR_ROWB;
+  constexpr int ORB = HL ? SR_HLB : SR_ROWB;
   constexpr bool NEED5 = FULL, NEED8 = (MODE == SM_A);
   constexpr int WLB = FULL ? SR_WB_ALL : SR_WB_CONV;
 
@@ -94,9 +106,11 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   const long long tfirst = tlast;
 #endif
 
-  const size_t sample = (size_t)b * Tn * SR_ROWB;
+  const size_t sample = (size_t)b * Tn * XRB;                 // of x
+  const size_t sample_f = (size_t)b * Tn * FRB;               // of f (in or out)
+  const size_t sample_o = (size_t)b * Tn * ORB;               // of x' (out)
   const __amdgpu_buffer_rsrc_t rx =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + sample, 0, Tn * SR_ROWB, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + sample, 0, Tn * XRB, 0x00020000);
 
   // ---- LDS-DMA of one batch (pass F): 4 x 1 KB + 16 lanes; out-of-range rows (t < 0, t >= Tn) fail the range check and land as zeros
   int doff[5];
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   float ra[8], rb[8];
   __amdgpu_buffer_rsrc_t rf = rx;
   if constexpr (MODE == SM_A) {
-    rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.fprev)) + sample, 0, Tn * SR_ROWB, 0x00020000);
+    rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.fprev)) + sample_f, 0, Tn * FRB, 0x00020000);
     // deferred GroupNorm(8,64) of the previous block on this lane's 8 channels (one group): a = rstd * gamma, b = beta - mean * a
     const float* tprev = reinterpret_cast<const float*>(a.packed_prev + SR_WB_ALL);
     const float mu = st8[cg * 2], rs = st8[cg * 2 + 1];
@@ -196,12 +210,25 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int t = s0 - SR_H + 16 * k + irow + 8 * it;
-      const int off = t * SR_ROWB + cg * 32;
-      sx0[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-      sx1[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16, 0, 0);
+      if constexpr (XHL) {          // hi plane: 16 bytes of this lane's 8 channels; lo plane: their 8 bytes
+        sx0[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, t * SR_HLB + cg * 16, 0, 0);
+        const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rx, t * SR_HLB + 128 + cg * 8, 0, 0);
+        sx1[it] = u32x4{l[0], l[1], 0u, 0u};
+      } else {
+        const int off = t * SR_ROWB + cg * 32;
+        sx0[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+        sx1[it] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16, 0, 0);
+      }
       if constexpr (MODE == SM_A) {
-        sf0[it] = __builtin_amdgcn_raw_buffer_load_b128(rf, off, 0, 0);
-        sf1[it] = __builtin_amdgcn_raw_buffer_load_b128(rf, off + 16, 0, 0);
+        if constexpr (FHL) {
+          sf0[it] = __builtin_amdgcn_raw_buffer_load_b128(rf, t * SR_HLB + cg * 16, 0, 0);
+          const u32x2 l = __builtin_amdgcn_raw_buffer_load_b64(rf, t * SR_HLB + 128 + cg * 8, 0, 0);
+          sf1[it] = u32x4{l[0], l[1], 0u, 0u};
+        } else {
+          const int off = t * SR_ROWB + cg * 32;
+          sf0[it] = __builtin_amdgcn_raw_buffer_load_b128(rf, off, 0, 0);
+          sf1[it] = __builtin_amdgcn_raw_buffer_load_b128(rf, off + 16, 0, 0);
+        }
       }
     }
   };
@@ -211,36 +238,64 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
       const int r = irow + 8 * it;
       const int t = s0 - SR_H + 16 * k + r;
       float v[8];
-      if constexpr (MODE == SM_A) {
-        float xv[8];
-        if constexpr (XPAIR) {
-          const f16x8_t h = __builtin_bit_cast(f16x8_t, sx0[it]), l = __builtin_bit_cast(f16x8_t, sx1[it]);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) xv[e] = (float)h[e] + (float)l[e];
-        } else {
-          const f32x4 p = __builtin_bit_cast(f32x4, sx0[it]), q = __builtin_bit_cast(f32x4, sx1[it]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { xv[e] = p[e]; xv[4 + e] = q[e]; }
-        }
-        const f32x4 fp = __builtin_bit_cast(f32x4, sf0[it]), fq = __builtin_bit_cast(f32x4, sf1[it]);
-        const bool inside = t >= 0 && t < Tn;        // rows outside the sample are the conv's zero padding, not b
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = inside ? ra[e] * (e < 4 ? fp[e] : fq[e - 4]) + rb[e] + xv[e] : 0.f;
+      u32x4 uh, ul;
+      if constexpr (MODE == SM_F && HL) {
+        // x' as hl8: the hi plane is the operand image's hi half as it is, the lo bytes widen to f16 exactly (no fp32 round trip)
+        uh = sx0[it];
+        ul = hl8_lo_f16(u32x2{sx1[it][0], sx1[it][1]});
       } else {
-        const f32x4 p = __builtin_bit_cast(f32x4, sx0[it]), q = __builtin_bit_cast(f32x4, sx1[it]);   // (zeros outside the sample)
+        if constexpr (MODE == SM_A) {
+          float xv[8], fv[8];
+          if constexpr (XHL) {
+            hl8_decode(sx0[it], u32x2{sx1[it][0], sx1[it][1]}, xv);
+          } else if constexpr (XPAIR) {
+            const f16x8_t h = __builtin_bit_cast(f16x8_t, sx0[it]), l = __builtin_bit_cast(f16x8_t, sx1[it]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = p[e]; v[4 + e] = q[e]; }
+            for (int e = 0; e < 8; ++e) xv[e] = (float)h[e] + (float)l[e];
+          } else {
+            const f32x4 p = __builtin_bit_cast(f32x4, sx0[it]), q = __builtin_bit_cast(f32x4, sx1[it]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[e] = p[e]; xv[4 + e] = q[e]; }
+          }
+          if constexpr (FHL) {
+            hl8_decode(sf0[it], u32x2{sf1[it][0], sf1[it][1]}, fv);
+          } else {
+            const f32x4 fp = __builtin_bit_cast(f32x4, sf0[it]), fq = __builtin_bit_cast(f32x4, sf1[it]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fv[e] = fp[e]; fv[4 + e] = fq[e]; }
+          }
+          const bool inside = t >= 0 && t < Tn;        // rows outside the sample are the conv's zero padding, not b
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = inside ? ra[e] * fv[e] + rb[e] + xv[e] : 0.f;
+        } else {
+          const f32x4 p = __builtin_bit_cast(f32x4, sx0[it]), q = __builtin_bit_cast(f32x4, sx1[it]);   // (zeros outside the sample)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = p[e]; v[4 + e] = q[e]; }
+        }
+        if constexpr (MODE == SM_A && HL) {
+          // the stored row IS what every later pass sees: stage 1 below (the statistics of v') runs on the hl8 value as well
+          const Hl8 e8 = hl8_encode(v);
+          uh = e8.hi;
+          ul = hl8_lo_f16(e8.lo);
+          if (t >= s0 && t < s0 + a.L && t < Tn) {      // the span's own rows leave for HBM here, once
+            char* o = reinterpret_cast<char*>(a.out) + sample_o + (size_t)t * SR_HLB;
+            *reinterpret_cast<u32x4*>(o + cg * 16) = e8.hi;
+            *reinterpret_cast<u32x2*>(o + 128 + cg * 8) = e8.lo;
+          }
+        } else {
+          uint32_t h[4], l[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) M::split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+          uh = u32x4{h[0], h[1], h[2], h[3]};
+          ul = u32x4{l[0], l[1], l[2], l[3]};
+        }
       }
-      uint32_t h[4], l[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) M::split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
-      const u32x4 uh = {h[0], h[1], h[2], h[3]}, ul = {l[0], l[1], l[2], l[3]};
       char* p = lds + ring + slot * SR_SLOT + r * SR_RS + cg * 32;
       *reinterpret_cast<u32x4*>(p) = uh;
       *reinterpret_cast<u32x4*>(p + 16) = ul;
-      if constexpr (MODE == SM_A) {
+      if constexpr (MODE == SM_A && !HL) {
         if (t >= s0 && t < s0 + a.L && t < Tn) {      // the span's own rows leave for HBM here, once
-          char* o = reinterpret_cast<char*>(a.out) + sample + (size_t)t * SR_ROWB + cg * 32;
+          char* o = reinterpret_cast<char*>(a.out) + sample_o + (size_t)t * SR_ROWB + cg * 32;
           *reinterpret_cast<u32x4*>(o) = uh;
           *reinterpret_cast<u32x4*>(o + 16) = ul;
         }
@@ -259,7 +314,7 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
   }
 
   const __amdgpu_buffer_rsrc_t ro =
-      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + sample, 0, FULL ? Tn * SR_ROWB : 0, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.out) + sample_f, 0, FULL ? Tn * FRB : 0, 0x00020000);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 
   // ---- stage 1 of one column tile into v (U = slot of the tile's first batch); xb0 keeps the tap-0 operands for the residual 1x1.
@@ -435,9 +490,22 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float q = ok ? f[m][r] : 0.f; s1[m] += q; s2[m] += q * q; }
         }
-        const int vo = (t0 + col) * SR_ROWB + 16 * g;
+        if constexpr (FHL) {          // this lane's 4 channels of M-tile m: 8 bytes of the hi plane, 4 of the lo plane
+          const int vo = (t0 + col) * SR_HLB;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f[m]), ro, vo + 64 * m, 0, 0);
+          for (int m = 0; m < 4; ++m) {
+            const uint32_t h0 = pack_f16(f[m][0], f[m][1]), h1 = pack_f16(f[m][2], f[m][3]);
+            const f16x2_t a0 = __builtin_bit_cast(f16x2_t, h0), a1 = __builtin_bit_cast(f16x2_t, h1);
+            const uint32_t l4 = hl8_pack4((f[m][0] - (float)a0[0]) * SR_LOS, (f[m][1] - (float)a0[1]) * SR_LOS,
+                                          (f[m][2] - (float)a1[0]) * SR_LOS, (f[m][3] - (float)a1[1]) * SR_LOS);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, ro, vo + 32 * m + 8 * g, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(l4, ro, vo + 128 + 16 * m + 4 * g, 0, 0);
+          }
+        } else {
+          const int vo = (t0 + col) * SR_ROWB + 16 * g;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f[m]), ro, vo + 64 * m, 0, 0);
+        }
       }
     };
     auto finish_only = [&]() {
@@ -559,7 +627,7 @@ __global__ __launch_bounds__(SR_NW * 64) void mrf_stream_kernel(SrArgs a) {
 }
 
 // the chain's materialised output (mv_mrf_chain_fwd_cl): out = a f + b + x as fp32 rows; x fp32 or pair rows
-template <bool XPAIR>
+template <bool XPAIR, bool HL>      // HL: f is hl8 rows, and so is x when XPAIR
 __global__ __launch_bounds__(256) void mrf_stream_final_kernel(const float* __restrict__ f, const void* __restrict__ x,
                                                                const float* __restrict__ part8, const float* __restrict__ tab,
                                                                float* __restrict__ out, int Tn, int nwg, float eps) {
@@ -585,7 +653,10 @@ __global__ __launch_bounds__(256) void mrf_stream_final_kernel(const float* __re
     const long t = i >> 3;
     const int cg = (int)(i & 7);
     float xv[8];
-    if constexpr (XPAIR) {
+    if constexpr (XPAIR && HL) {
+      const char* p = reinterpret_cast<const char*>(x) + ((size_t)b * Tn + t) * SR_HLB;
+      hl8_decode(*reinterpret_cast<const u32x4*>(p + cg * 16), *reinterpret_cast<const u32x2*>(p + 128 + cg * 8), xv);
+    } else if constexpr (XPAIR) {
       const char* p = reinterpret_cast<const char*>(x) + (base + (size_t)t * 64) * 4 + cg * 32;
       const f16x8_t h = *reinterpret_cast<const f16x8_t*>(p), l = *reinterpret_cast<const f16x8_t*>(p + 16);
 #pragma unroll
@@ -596,8 +667,18 @@ __global__ __launch_bounds__(256) void mrf_stream_final_kernel(const float* __re
 #pragma unroll
       for (int e = 0; e < 4; ++e) { xv[e] = u[e]; xv[4 + e] = w[e]; }
     }
-    const float* fp = f + base + (size_t)t * 64 + cg * 8;
-    const f32x4 fu = *reinterpret_cast<const f32x4*>(fp), fw = *reinterpret_cast<const f32x4*>(fp + 4);
+    f32x4 fu, fw;
+    if constexpr (HL && SR_FHL) {
+      const char* p = reinterpret_cast<const char*>(f) + ((size_t)b * Tn + t) * SR_HLB;
+      float fv[8];
+      hl8_decode(*reinterpret_cast<const u32x4*>(p + cg * 16), *reinterpret_cast<const u32x2*>(p + 128 + cg * 8), fv);
+      fu = f32x4{fv[0], fv[1], fv[2], fv[3]};
+      fw = f32x4{fv[4], fv[5], fv[6], fv[7]};
+    } else {
+      const float* fp = f + base + (size_t)t * 64 + cg * 8;
+      fu = *reinterpret_cast<const f32x4*>(fp);
+      fw = *reinterpret_cast<const f32x4*>(fp + 4);
+    }
     f32x4 o0, o1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -619,11 +700,11 @@ static inline void sr_geometry(int B, int Tn, int* L, int* nwg) {
   *nwg = cdiv(tiles, tpw * SR_NW);
 }
 
-template <int MODE, bool XPAIR>
+template <int MODE, bool XPAIR, bool HL = false>
 static void sr_launch(const SrArgs& a, int B, hipStream_t stream) {
   constexpr bool FULL = (MODE == SM_F0 || MODE == SM_F);
   const size_t lds = (size_t)(FULL ? SR_WB_ALL : SR_WB_CONV) + MRF_TAB_FLOATS * 4 + (32 + 16 + SR_NW * 32) * 4 + 512 * 8 + (size_t)SR_NW * SR_RING;
-  auto k = mrf_stream_kernel<MODE, XPAIR>;
+  auto k = mrf_stream_kernel<MODE, XPAIR, HL>;
   static bool set = false;
   if (!set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
   hipLaunchKernelGGL(k, dim3(a.nwg, B), dim3(SR_NW * 64), lds, stream, a);
@@ -656,6 +737,10 @@ int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, in
   { const char* e = getenv("MV_SR_DBG"); a.dbg = e ? atoi(e) : 0; }
   const void* xi = x;
   bool xi_pair = x_pair_in != 0;               // the producer already wrote pair rows (the last upsampler's streaming kernel)
+  // hl8 rows between the blocks (MV_MRF_HL8=0: the 256-byte pair / fp32 rows of the first streaming form; pair-row input keeps them)
+  static int hl_env = -1;
+  if (hl_env < 0) { const char* e = getenv("MV_MRF_HL8"); hl_env = e ? atoi(e) : 1; }
+  const bool hl = hl_env != 0 && !xi_pair;
   for (int i = 0; i < nblocks; ++i) {
     a.packed = (const char*)packed[i];
     if (i == 0) {
@@ -663,16 +748,20 @@ int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, in
       a.part5_in = nullptr; a.part5_out = part5; a.part8_in = nullptr; a.part8_out = nullptr;
       if (xi_pair) sr_launch<SM_V0, true>(a, B, stream); else sr_launch<SM_V0, false>(a, B, stream);
       a.out = fbuf; a.part5_in = part5; a.part5_out = nullptr; a.part8_out = part8;
-      if (xi_pair) sr_launch<SM_F, true>(a, B, stream); else sr_launch<SM_F0, false>(a, B, stream);
+      if (xi_pair) sr_launch<SM_F, true>(a, B, stream);
+      else if (hl) sr_launch<SM_F0, false, true>(a, B, stream);
+      else sr_launch<SM_F0, false>(a, B, stream);
     } else {
       char* xn = xbuf[i & 1];
       a.x = xi; a.fprev = fbuf; a.out = xn; a.packed_prev = (const char*)packed[i - 1];
       a.part5_in = nullptr; a.part5_out = part5; a.part8_in = part8; a.part8_out = nullptr;
-      if (xi_pair) sr_launch<SM_A, true>(a, B, stream); else sr_launch<SM_A, false>(a, B, stream);
+      if (hl) { if (xi_pair) sr_launch<SM_A, true, true>(a, B, stream); else sr_launch<SM_A, false, true>(a, B, stream); }
+      else if (xi_pair) sr_launch<SM_A, true>(a, B, stream);
+      else sr_launch<SM_A, false>(a, B, stream);
       xi = xn; xi_pair = true;
       a.x = xi; a.fprev = nullptr; a.out = fbuf; a.packed_prev = nullptr;
       a.part5_in = part5; a.part5_out = nullptr; a.part8_in = nullptr; a.part8_out = part8;
-      sr_launch<SM_F, true>(a, B, stream);
+      if (hl) sr_launch<SM_F, true, true>(a, B, stream); else sr_launch<SM_F, true>(a, B, stream);
     }
   }
 #ifdef MV_SR_TIMING
@@ -704,13 +793,19 @@ int mvi_mrf_chain_stream(const void* x, void* out, const void* const* packed, in
   if (out) {
     const long items = (long)Tn * 8;
     const int gx = (int)((items + 255) / 256 > 1024 ? 1024 : (items + 255) / 256);
-    if (xi_pair)
-      hipLaunchKernelGGL(mrf_stream_final_kernel<true>, dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
+    if (hl && xi_pair)
+      hipLaunchKernelGGL((mrf_stream_final_kernel<true, true>), dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
+    else if (hl)
+      hipLaunchKernelGGL((mrf_stream_final_kernel<false, true>), dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
+    else if (xi_pair)
+      hipLaunchKernelGGL((mrf_stream_final_kernel<true, false>), dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
     else
-      hipLaunchKernelGGL(mrf_stream_final_kernel<false>, dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
+      hipLaunchKernelGGL((mrf_stream_final_kernel<false, false>), dim3(gx, B), dim3(256), 0, stream, fbuf, xi, part8, tabp, (float*)out, Tn, nwg, eps);
     return MV_OK;
   }
-  *f_last = fbuf; *x_last = xi; *x_last_pair = xi_pair ? 1 : 0;
+  // x_last_pair: 0 = x and f fp32 rows, 1 = x pair rows, 2 = x and f hl8 rows, 3 = x fp32 with f hl8 (one-block chain), 4 = x hl8, f fp32
+  *f_last = fbuf; *x_last = xi;
+  *x_last_pair = !hl ? (xi_pair ? 1 : 0) : SR_FHL ? (xi_pair ? 2 : 3) : (xi_pair ? 4 : 0);
   *part8_last = part8; *tab_last = tabp; *nwg_last = nwg;
   return MV_OK;
 }

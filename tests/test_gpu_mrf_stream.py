@@ -81,8 +81,12 @@ def test_full_c2_batch_mixed_w16_meets_north_star(H):
         print(f"[parity] mixed through up1 + MRF two-product operands: waveform rel-L2 vs oracle {[f'{e:.2e}' for e in errs]}")
         assert max(errs) < 1e-3, errs
         # stage outputs of the same mode go through the materialising chain entry (mv_mrf_chain_fwd_cl)
+        # (a batch of 2 sums its GroupNorm partials in another grouping than the batch of 32: 1e-7 differences, which the 15-bit rows
+        #  between the blocks turn into an occasional flipped last bit - the two runs agree to the rows' rounding level, not to fp32's)
         st = gen(mel[:2].cuda(), spk[:2].cuda(), emo[:2].cuda(), return_stages=True)
-        assert O.rel_l2(st["wave"].cpu(), wave[:2].cpu()) < 1e-5
+        e2 = O.rel_l2(st["wave"].cpu(), wave[:2].cpu())
+        print(f"[parity] stage-wise entry, batch of 2, vs the fused batch of 32: {e2:.2e}")
+        assert e2 < 1e-4
     with pytest.raises(ValueError):
         gen.set_mixed_precision("up1", mrf_weights="bf16")
 
@@ -125,7 +129,8 @@ def _unpair(y):
 @pytest.mark.parametrize("B,T", [(2, 48), (3, 700), (1, 17), (2, 4100)])
 def test_stream_chain_takes_pair_rows(H, B, T):
     """MV_F32_W16P: the chain fed with its own row format (what the last upsampler's streaming kernel writes) - the first pass reads it
-    by LDS-DMA - equals the chain fed with fp32 rows up to the 22-bit representation of the input (2^-22 relative)."""
+    by LDS-DMA - equals the chain fed with fp32 rows up to the representation of the rows (one block: the 22-bit input, 2^-22
+    relative - plus f as a 15-bit hl8 row on the fp32-row side; more blocks: both of that side's streams are hl8 rows, 2^-15)."""
     from hifigan_modified.fused import MrfChain, mrf_fused_for
     blks, _ = _blocks(H)
     chain = MrfChain([mrf_fused_for(bk) for bk in blks])
@@ -137,7 +142,8 @@ def test_stream_chain_takes_pair_rows(H, B, T):
             b = chain.forward_cl(_pair_rows(xc), n, w16=True, x_pair=True)
             b2 = chain.forward_cl(_pair_rows(xc), n, w16=True, x_pair=True)
             assert torch.equal(b, b2)
-            assert O.rel_l2(b.cpu(), a.cpu()) < 2e-6, (n, O.rel_l2(b.cpu(), a.cpu()))
+            # (the fp32-row entry keeps its streams between the blocks as 15-bit hl8 rows, the pair-row entry as 22-bit pair rows)
+            assert O.rel_l2(b.cpu(), a.cpu()) < (1e-5 if n == 1 else 1e-4), (n, O.rel_l2(b.cpu(), a.cpu()))
 
 
 @pytest.mark.parametrize("B,T", [(2, 64), (3, 1000), (32, 4096)])
